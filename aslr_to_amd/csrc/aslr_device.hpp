@@ -1,0 +1,686 @@
+// aslr_device.hpp -- per-knot model arithmetic for gfx950, one LANE per (trajectory, knot).
+//
+// Everything here is thread-local and fully unrolled over the compile-time joint count NJ, so the
+// small vectors/matrices live in VGPRs.  It implements, for a fixed-base serial revolute chain:
+//   * SEA / VSA free-forward-dynamics calc   (python/aslr_to/free_fwddyn_asr.py:20-56,
+//                                            python/aslr_to/free_fwddyn_vsa.py:20-57)
+//   * their calcDiff                         (free_fwddyn_asr.py:58-92, free_fwddyn_vsa.py:59-94)
+//   * the semi-implicit Euler step           (python/aslr_to/integrated_action.py:13-42)
+//   * the cost stack of the example scripts  
+// The rigid-body pieces Pinocchio provides to the reference (computeAllTerms, computeRNEADerivatives,
+// frame placement / LOCAL frame Jacobian, log6 / Jlog6) are written here directly: RNEA for nle,
+// unit-acceleration RNEA passes for M, forward-mode (tangent) RNEA for dtau_dq / dtau_dv.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "../../include/aslr_to_amd.h"
+
+namespace aslr {
+
+#define ASLR_DEV __device__ __forceinline__
+#define ASLR_UNROLL _Pragma("unroll")
+
+// Device-side model: the ABI struct plus host-precomputed inverse of the motor inertia.
+struct DevModel {
+  aslr_model_t m;
+  double Binv[ASLR_MAX_NJ * ASLR_MAX_NJ];
+};
+struct DevDesc {
+  aslr_chain_t chain;
+  DevModel models[ASLR_MAX_MODELS];
+};
+
+// ---------------------------------------------------------------------------------------------
+// 3-D / spatial algebra (Pinocchio conventions: motion and force = [linear; angular])
+// ---------------------------------------------------------------------------------------------
+struct V3 { double x, y, z; };
+struct SV { V3 lin, ang; };
+struct M3 { double a[9]; };
+struct SE3d { M3 R; V3 p; };
+
+ASLR_DEV V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+ASLR_DEV V3 v3(const double *p) { return V3{p[0], p[1], p[2]}; }
+ASLR_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+ASLR_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+ASLR_DEV V3 operator*(double s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+ASLR_DEV V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+ASLR_DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+ASLR_DEV V3 cross(V3 a, V3 b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+ASLR_DEV V3 mul(const M3 &R, V3 v) {
+  return V3{R.a[0] * v.x + R.a[1] * v.y + R.a[2] * v.z, R.a[3] * v.x + R.a[4] * v.y + R.a[5] * v.z,
+            R.a[6] * v.x + R.a[7] * v.y + R.a[8] * v.z};
+}
+ASLR_DEV V3 mulT(const M3 &R, V3 v) {
+  return V3{R.a[0] * v.x + R.a[3] * v.y + R.a[6] * v.z, R.a[1] * v.x + R.a[4] * v.y + R.a[7] * v.z,
+            R.a[2] * v.x + R.a[5] * v.y + R.a[8] * v.z};
+}
+ASLR_DEV M3 mul(const M3 &A, const M3 &B) {
+  M3 C;
+  ASLR_UNROLL for (int i = 0; i < 3; ++i)
+    ASLR_UNROLL for (int j = 0; j < 3; ++j)
+      C.a[3 * i + j] = A.a[3 * i] * B.a[j] + A.a[3 * i + 1] * B.a[3 + j] + A.a[3 * i + 2] * B.a[6 + j];
+  return C;
+}
+ASLR_DEV M3 mulTN(const M3 &A, const M3 &B) { // A^T B
+  M3 C;
+  ASLR_UNROLL for (int i = 0; i < 3; ++i)
+    ASLR_UNROLL for (int j = 0; j < 3; ++j)
+      C.a[3 * i + j] = A.a[i] * B.a[j] + A.a[3 + i] * B.a[3 + j] + A.a[6 + i] * B.a[6 + j];
+  return C;
+}
+ASLR_DEV M3 m3(const double *p) {
+  M3 R;
+  ASLR_UNROLL for (int i = 0; i < 9; ++i) R.a[i] = p[i];
+  return R;
+}
+ASLR_DEV SV operator+(SV a, SV b) { return SV{a.lin + b.lin, a.ang + b.ang}; }
+ASLR_DEV SV sv_zero() { return SV{V3{0, 0, 0}, V3{0, 0, 0}}; }
+// Rodrigues rotation about a unit axis (JointModelRevoluteUnaligned)
+ASLR_DEV M3 axis_angle(V3 ax, double q) {
+  double s, c;
+  sincos(q, &s, &c);
+  const double v = 1.0 - c;
+  M3 R;
+  R.a[0] = ax.x * ax.x * v + c;        R.a[1] = ax.x * ax.y * v - ax.z * s; R.a[2] = ax.x * ax.z * v + ax.y * s;
+  R.a[3] = ax.y * ax.x * v + ax.z * s; R.a[4] = ax.y * ax.y * v + c;        R.a[5] = ax.y * ax.z * v - ax.x * s;
+  R.a[6] = ax.z * ax.x * v - ax.y * s; R.a[7] = ax.z * ax.y * v + ax.x * s; R.a[8] = ax.z * ax.z * v + c;
+  return R;
+}
+ASLR_DEV SE3d se3_mul(const SE3d &A, const SE3d &B) { return SE3d{mul(A.R, B.R), mul(A.R, B.p) + A.p}; }
+// motion: child -> parent
+ASLR_DEV SV motion_act(const SE3d &M, SV m) {
+  V3 w = mul(M.R, m.ang);
+  return SV{mul(M.R, m.lin) + cross(M.p, w), w};
+}
+// motion: parent -> child
+ASLR_DEV SV motion_actinv(const SE3d &M, SV m) {
+  return SV{mulT(M.R, m.lin - cross(M.p, m.ang)), mulT(M.R, m.ang)};
+}
+// force: child -> parent
+ASLR_DEV SV force_act(const SE3d &M, SV f) {
+  V3 l = mul(M.R, f.lin);
+  return SV{l, mul(M.R, f.ang) + cross(M.p, l)};
+}
+ASLR_DEV SV crm(SV a, SV b) { return SV{cross(a.ang, b.lin) + cross(a.lin, b.ang), cross(a.ang, b.ang)}; }
+ASLR_DEV SV crf(SV a, SV f) { return SV{cross(a.ang, f.lin), cross(a.ang, f.ang) + cross(a.lin, f.lin)}; }
+ASLR_DEV SV inertia_mul(double mass, V3 c, const M3 &I, SV m) {
+  V3 l = mass * (m.lin - cross(c, m.ang));
+  return SV{l, mul(I, m.ang) + cross(c, l)};
+}
+
+// ---------------------------------------------------------------------------------------------
+// SE(3) log map and its Jacobian (Pinocchio 2.6 explog: acos on the trace, branch near pi)
+// ---------------------------------------------------------------------------------------------
+constexpr double kTaylorPrec = 1.220703125e-04; // eps^(1/4)
+constexpr double kPi = 3.14159265358979323846;
+
+ASLR_DEV double log3(const M3 &R, V3 &w) {
+  double tr = R.a[0] + R.a[4] + R.a[8], theta;
+  if (tr >= 3.0) { tr = 3.0; theta = 0.0; }
+  else if (tr <= -1.0) { tr = -1.0; theta = kPi; }
+  else theta = acos((tr - 1.0) / 2.0);
+  if (theta >= kPi - 1e-2) {
+    const double cphi = -(tr - 1.0) / 2.0;
+    const double beta = theta * theta / (1.0 + cphi);
+    const double t0 = (R.a[0] + cphi) * beta, t1 = (R.a[4] + cphi) * beta, t2 = (R.a[8] + cphi) * beta;
+    w.x = (R.a[7] > R.a[5] ? 1.0 : -1.0) * (t0 > 0.0 ? sqrt(t0) : 0.0);
+    w.y = (R.a[2] > R.a[6] ? 1.0 : -1.0) * (t1 > 0.0 ? sqrt(t1) : 0.0);
+    w.z = (R.a[3] > R.a[1] ? 1.0 : -1.0) * (t2 > 0.0 ? sqrt(t2) : 0.0);
+  } else {
+    const double t = ((theta > kTaylorPrec) ? theta / sin(theta) : 1.0) / 2.0;
+    w.x = t * (R.a[7] - R.a[5]);
+    w.y = t * (R.a[2] - R.a[6]);
+    w.z = t * (R.a[3] - R.a[1]);
+  }
+  return theta;
+}
+
+// r = log6(M).vector = [v; w] (residual_frame_placement.py:14-15); also returns theta and w.
+ASLR_DEV void log6(const SE3d &M, double *r, double &t, V3 &w) {
+  t = log3(M.R, w);
+  const double t2 = t * t;
+  double alpha, beta;
+  if (t < kTaylorPrec) {
+    alpha = 1.0 - t2 / 12.0 - t2 * t2 / 720.0;
+    beta = 1.0 / 12.0 + t2 / 720.0;
+  } else {
+    double st, ct;
+    sincos(t, &st, &ct);
+    alpha = t * st / (2.0 * (1.0 - ct));
+    beta = 1.0 / t2 - st / (2.0 * t * (1.0 - ct));
+  }
+  const V3 wxp = cross(w, M.p);
+  const double wp = dot(w, M.p);
+  r[0] = alpha * M.p.x - 0.5 * wxp.x + beta * wp * w.x;
+  r[1] = alpha * M.p.y - 0.5 * wxp.y + beta * wp * w.y;
+  r[2] = alpha * M.p.z - 0.5 * wxp.z + beta * wp * w.z;
+  r[3] = w.x; r[4] = w.y; r[5] = w.z;
+}
+
+ASLR_DEV M3 jlog3(double theta, V3 w) {
+  const double t2 = theta * theta;
+  double alpha, diag;
+  if (theta < kTaylorPrec) {
+    alpha = 1.0 / 12.0 + t2 / 720.0;
+    diag = 0.5 * (2.0 - t2 / 6.0);
+  } else {
+    double st, ct;
+    sincos(theta, &st, &ct);
+    const double st_1mct = st / (1.0 - ct);
+    alpha = 1.0 / t2 - st_1mct / (2.0 * theta);
+    diag = 0.5 * (theta * st_1mct);
+  }
+  const double wv[3] = {w.x, w.y, w.z};
+  M3 J;
+  ASLR_UNROLL for (int i = 0; i < 3; ++i)
+    ASLR_UNROLL for (int j = 0; j < 3; ++j) J.a[3 * i + j] = alpha * wv[i] * wv[j];
+  J.a[0] += diag; J.a[4] += diag; J.a[8] += diag;
+  J.a[1] -= 0.5 * w.z; J.a[2] += 0.5 * w.y;
+  J.a[3] += 0.5 * w.z; J.a[5] -= 0.5 * w.x;
+  J.a[6] -= 0.5 * w.y; J.a[7] += 0.5 * w.x;
+  return J;
+}
+
+// Jlog6(M) = [[A, B], [0, A]] (residual_frame_placement.py:19); theta, w from log6
+ASLR_DEV void jlog6(const SE3d &M, double t, V3 w, M3 &A, M3 &Bm) {
+  const double t2 = t * t;
+  double beta, bdot;
+  if (t < kTaylorPrec) {
+    beta = 1.0 / 12.0 + t2 / 720.0;
+    bdot = 1.0 / 360.0;
+  } else {
+    const double tinv = 1.0 / t, t2inv = tinv * tinv;
+    double st, ct;
+    sincos(t, &st, &ct);
+    const double inv_2_2ct = 1.0 / (2.0 * (1.0 - ct));
+    beta = t2inv - st * tinv * inv_2_2ct;
+    bdot = -2.0 * t2inv * t2inv + (1.0 + st * tinv) * t2inv * inv_2_2ct;
+  }
+  A = jlog3(t, w);
+  const V3 p = M.p;
+  const double wTp = dot(w, p);
+  const V3 v3t = (bdot * wTp) * w - (t2 * bdot + 2.0 * beta) * p;
+  const double vv[3] = {v3t.x, v3t.y, v3t.z}, wv[3] = {w.x, w.y, w.z}, pv[3] = {p.x, p.y, p.z};
+  M3 Cm;
+  ASLR_UNROLL for (int i = 0; i < 3; ++i)
+    ASLR_UNROLL for (int j = 0; j < 3; ++j) Cm.a[3 * i + j] = vv[i] * wv[j] + beta * wv[i] * pv[j];
+  Cm.a[0] += wTp * beta; Cm.a[4] += wTp * beta; Cm.a[8] += wTp * beta;
+  Cm.a[1] -= 0.5 * p.z; Cm.a[2] += 0.5 * p.y;
+  Cm.a[3] += 0.5 * p.z; Cm.a[5] -= 0.5 * p.x;
+  Cm.a[6] -= 0.5 * p.y; Cm.a[7] += 0.5 * p.x;
+  Bm = mul(Cm, A);
+}
+
+// ---------------------------------------------------------------------------------------------
+// small dense helpers on register arrays
+// ---------------------------------------------------------------------------------------------
+// Cholesky LL^T in place (lower); returns true on a non-positive pivot
+template <int N>
+ASLR_DEV bool chol(double (&A)[N][N]) {
+  bool bad = false;
+  ASLR_UNROLL for (int j = 0; j < N; ++j) {
+    double d = A[j][j];
+    ASLR_UNROLL for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+    if (!(d > 0.0)) bad = true;
+    d = sqrt(d);
+    A[j][j] = d;
+    ASLR_UNROLL for (int i = j + 1; i < N; ++i) {
+      double s = A[i][j];
+      ASLR_UNROLL for (int k = 0; k < j; ++k) s -= A[i][k] * A[j][k];
+      A[i][j] = s / d;
+    }
+  }
+  return bad;
+}
+template <int N>
+ASLR_DEV void chol_solve(const double (&L)[N][N], double (&b)[N]) {
+  ASLR_UNROLL for (int i = 0; i < N; ++i) {
+    double s = b[i];
+    ASLR_UNROLL for (int k = 0; k < i; ++k) s -= L[i][k] * b[k];
+    b[i] = s / L[i][i];
+  }
+  ASLR_UNROLL for (int i = N - 1; i >= 0; --i) {
+    double s = b[i];
+    ASLR_UNROLL for (int k = i + 1; k < N; ++k) s -= L[k][i] * b[k];
+    b[i] = s / L[i][i];
+  }
+}
+template <int N>
+ASLR_DEV void spd_inverse(const double (&A)[N][N], double (&Ainv)[N][N]) {
+  double L[N][N];
+  ASLR_UNROLL for (int i = 0; i < N; ++i)
+    ASLR_UNROLL for (int j = 0; j < N; ++j) L[i][j] = A[i][j];
+  chol<N>(L);
+  ASLR_UNROLL for (int j = 0; j < N; ++j) {
+    double e[N];
+    ASLR_UNROLL for (int i = 0; i < N; ++i) e[i] = (i == j) ? 1.0 : 0.0;
+    chol_solve<N>(L, e);
+    ASLR_UNROLL for (int i = 0; i < N; ++i) Ainv[i][j] = e[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// chain dynamics
+// ---------------------------------------------------------------------------------------------
+template <int NJ>
+struct Kin { // forward kinematics shared by everything at one q
+  SE3d liMi[NJ];
+};
+
+template <int NJ>
+ASLR_DEV void joint_placements(const aslr_chain_t &c, const double *q, Kin<NJ> &k) {
+  ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+    const M3 Rj = axis_angle(v3(c.axis[i]), q[i]);
+    k.liMi[i].R = mul(m3(c.joint_R[i]), Rj);
+    k.liMi[i].p = v3(c.joint_p[i]);
+  }
+}
+
+// RNEA(q, v, a) with gravity; keeps what the tangent passes need when KEEP is set.
+template <int NJ>
+struct RneaWs {
+  SV v[NJ], h[NJ], F[NJ], vJ[NJ], Xv[NJ], Xa[NJ];
+};
+
+template <int NJ, bool KEEP>
+ASLR_DEV void rnea(const aslr_chain_t &c, const Kin<NJ> &k, const double *v, const double *a, V3 grav,
+                   double *tau, RneaWs<NJ> &w) {
+  SV vp = sv_zero(), ap = SV{neg(grav), V3{0, 0, 0}};
+  SV f[NJ];
+  ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+    const V3 ax = v3(c.axis[i]);
+    const SV vJ = SV{V3{0, 0, 0}, v[i] * ax};
+    const SV Xv = motion_actinv(k.liMi[i], vp);
+    const SV vi = Xv + vJ;
+    const SV Xa = motion_actinv(k.liMi[i], ap);
+    SV ai = Xa + crm(vi, vJ);
+    ai.ang = ai.ang + a[i] * ax;
+    const V3 com = v3(c.com[i]);
+    const M3 I = m3(c.inertia[i]);
+    const SV h = inertia_mul(c.mass[i], com, I, vi);
+    f[i] = inertia_mul(c.mass[i], com, I, ai) + crf(vi, h);
+    if (KEEP) { w.v[i] = vi; w.h[i] = h; w.vJ[i] = vJ; w.Xv[i] = Xv; w.Xa[i] = Xa; }
+    vp = vi;
+    ap = ai;
+  }
+  ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
+    tau[i] = dot(v3(c.axis[i]), f[i].ang);
+    if (i > 0) f[i - 1] = f[i - 1] + force_act(k.liMi[i], f[i]);
+    if (KEEP) w.F[i] = f[i];
+  }
+}
+
+// joint-space inertia: column j = RNEA(q, 0, e_j) without gravity; symmetrised like the Python
+// binding's data.M
+template <int NJ>
+ASLR_DEV void crba(const aslr_chain_t &c, const Kin<NJ> &k, double (&M)[NJ][NJ]) {
+  ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+    SV ap = sv_zero();
+    SV f[NJ];
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+      if (i < j) { f[i] = sv_zero(); continue; }
+      SV ai = (i == j) ? sv_zero() : motion_actinv(k.liMi[i], ap);
+      if (i == j) ai.ang = v3(c.axis[i]);
+      f[i] = inertia_mul(c.mass[i], v3(c.com[i]), m3(c.inertia[i]), ai);
+      ap = ai;
+    }
+    ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
+      M[i][j] = dot(v3(c.axis[i]), f[i].ang);
+      if (i > 0) f[i - 1] = f[i - 1] + force_act(k.liMi[i], f[i]);
+    }
+  }
+  ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+    ASLR_UNROLL for (int j = i + 1; j < NJ; ++j) {
+      const double s = 0.5 * (M[i][j] + M[j][i]);
+      M[i][j] = s;
+      M[j][i] = s;
+    }
+}
+
+// computeRNEADerivatives by forward-mode differentiation of the recursion (one direction per
+// column): dtau_dq[i][j], dtau_dv[i][j].  `w` comes from rnea<KEEP=true>(q, v, a).
+template <int NJ>
+ASLR_DEV void rnea_derivatives(const aslr_chain_t &c, const Kin<NJ> &k, const RneaWs<NJ> &w,
+                               double (&dq)[NJ][NJ], double (&dv)[NJ][NJ]) {
+  ASLR_UNROLL for (int kind = 0; kind < 2; ++kind) {
+    ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+      const SV Sj = SV{V3{0, 0, 0}, v3(c.axis[j])};
+      SV dvp = sv_zero(), dap = sv_zero();
+      SV df[NJ];
+      ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+        if (i < j) { df[i] = sv_zero(); continue; } // nothing upstream of joint j moves
+        SV dvi = (i == j) ? sv_zero() : motion_actinv(k.liMi[i], dvp);
+        SV dai = (i == j) ? sv_zero() : motion_actinv(k.liMi[i], dap);
+        if (i == j) {
+          if (kind == 0) { dvi = crm(w.Xv[i], Sj); dai = crm(w.Xa[i], Sj); }
+          else { dvi = Sj; dai = crm(w.v[i], Sj); }
+        }
+        dai = dai + crm(dvi, w.vJ[i]);
+        const V3 com = v3(c.com[i]);
+        const M3 I = m3(c.inertia[i]);
+        df[i] = inertia_mul(c.mass[i], com, I, dai) + crf(dvi, w.h[i]) +
+                crf(w.v[i], inertia_mul(c.mass[i], com, I, dvi));
+        dvp = dvi;
+        dap = dai;
+      }
+      ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
+        const double val = dot(v3(c.axis[i]), df[i].ang);
+        if (kind == 0) dq[i][j] = val; else dv[i][j] = val;
+        if (i > 0) {
+          df[i - 1] = df[i - 1] + force_act(k.liMi[i], df[i]);
+          if (kind == 0 && i == j) df[i - 1] = df[i - 1] + force_act(k.liMi[i], crf(Sj, w.F[i]));
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// knot-level results
+// ---------------------------------------------------------------------------------------------
+// Compact derivative set of one knot.  The continuous Fx of the SEA/VSA models has the block
+// structure [ddq_dq | Minv K | ddq_dv | 0 ; Binv K | -Binv K | 0 | 0] (free_fwddyn_asr.py:78-86),
+// Lxx of the package's cost types is (top-left nj x nj block) + diagonal, Luu diagonal, Lxu = 0.
+template <int NJ, int NU>
+struct KnotDiff {
+  double Aqq[NJ][NJ], Aqm[NJ][NJ], Aqv[NJ][NJ], Bk[NJ][NJ]; // da_dx blocks
+  double Ful[NJ][NU], Fum[NJ][NU];                          // da_du link / motor rows
+  double Lx[4 * NJ], Lu[NU], Lqq[NJ][NJ], Lxxd[4 * NJ], Luud[NU];
+};
+
+template <int NJ, int DAM> struct ModelDims {
+  static constexpr int nx = 4 * NJ;
+  static constexpr int nu = DAM == ASLR_DAM_VSA ? 2 * NJ : NJ;
+};
+
+// calc (+ calcDiff when DIFF): x[4NJ], u[NU] -> xnext, cost (+ compact derivatives).
+// u == nullptr selects the model's "u is None" default (terminal node).
+template <int NJ, int DAM, bool DIFF>
+ASLR_DEV void knot_eval(const aslr_chain_t &c, const DevModel &dm, const double *frame_ref,
+                        const double (&x)[4 * NJ], const double *u_in, double (&xnext)[4 * NJ],
+                        double &cost_out, KnotDiff<NJ, ModelDims<NJ, DAM>::nu> *kd,
+                        double *xout_o = nullptr) {
+  constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
+  const aslr_model_t &m = dm.m;
+  double u[NU];
+  if (u_in) {
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = u_in[i];
+  } else {
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = (DAM == ASLR_DAM_VSA && i >= NJ) ? 3.0 : 0.0;
+  }
+  double q[NJ], v[NJ], dqm[NJ];
+  ASLR_UNROLL for (int i = 0; i < NJ; ++i) { q[i] = x[i]; v[i] = x[2 * NJ + i]; dqm[i] = x[i] - x[NJ + i]; }
+
+  // stiffness / coupling torque / motor torque
+  double Kmat[NJ][NJ], tau_m[NJ], tau_c[NJ];
+  if (DAM == ASLR_DAM_VSA) {
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) Kmat[i][j] = (i == j) ? u[NJ + i] : 0.0;
+      tau_m[i] = u[i];
+    }
+  } else {
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+      double s = 0.0;
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) { Kmat[i][j] = m.K[i * NJ + j]; s += m.S[i * NU + j] * u[j]; }
+      tau_m[i] = s;
+    }
+  }
+  ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+    double s = 0.0;
+    ASLR_UNROLL for (int j = 0; j < NJ; ++j) s += Kmat[i][j] * dqm[j];
+    tau_c[i] = s;
+  }
+
+  Kin<NJ> kin;
+  joint_placements<NJ>(c, q, kin);
+  const V3 grav = v3(c.gravity);
+  double M[NJ][NJ], Minv[NJ][NJ], nle[NJ], zero[NJ];
+  ASLR_UNROLL for (int i = 0; i < NJ; ++i) zero[i] = 0.0;
+  RneaWs<NJ> ws;
+  rnea<NJ, false>(c, kin, v, zero, grav, nle, ws);
+  crba<NJ>(c, kin, M);
+  spd_inverse<NJ>(M, Minv);
+
+  double xout[2 * NJ];
+  ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+    double s = 0.0, s2 = 0.0;
+    ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+      s += Minv[i][j] * (-nle[j] - tau_c[j]);
+      s2 += dm.Binv[i * NJ + j] * (tau_m[j] + tau_c[j]);
+    }
+    xout[i] = s;
+    xout[NJ + i] = s2;
+  }
+  if (xout_o) {
+    ASLR_UNROLL for (int i = 0; i < 2 * NJ; ++i) xout_o[i] = xout[i];
+  }
+  // semi-implicit Euler (integrated_action.py:23-24)
+  const double dt = m.dt;
+  ASLR_UNROLL for (int i = 0; i < 2 * NJ; ++i) {
+    xnext[i] = x[i] + (x[2 * NJ + i] * dt + xout[i] * dt * dt);
+    xnext[2 * NJ + i] = x[2 * NJ + i] + xout[i] * dt;
+  }
+
+  if (DIFF) {
+    double ddq[NJ][NJ], ddv[NJ][NJ];
+    rnea<NJ, true>(c, kin, v, xout, grav, zero /*discarded tau*/, ws);
+    rnea_derivatives<NJ>(c, kin, ws, ddq, ddv);
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+        double sq = 0.0, sk = 0.0, sv = 0.0, bk = 0.0;
+        ASLR_UNROLL for (int l = 0; l < NJ; ++l) {
+          sq += Minv[i][l] * (-ddq[l][j] - Kmat[l][j]);
+          sk += Minv[i][l] * Kmat[l][j];
+          sv += Minv[i][l] * (-ddv[l][j]);
+          bk += dm.Binv[i * NJ + l] * Kmat[l][j];
+        }
+        kd->Aqq[i][j] = sq; kd->Aqm[i][j] = sk; kd->Aqv[i][j] = sv; kd->Bk[i][j] = bk;
+      }
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+      ASLR_UNROLL for (int j = 0; j < NU; ++j) { kd->Ful[i][j] = 0.0; kd->Fum[i][j] = 0.0; }
+    if (DAM == ASLR_DAM_VSA) {
+      ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+        ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+          kd->Ful[i][NJ + j] = Minv[i][j] * (-x[j] + x[NJ + j]);
+          kd->Fum[i][NJ + j] = dm.Binv[i * NJ + j] * (x[j] - x[NJ + j]);
+          kd->Fum[i][j] = dm.Binv[i * NJ + j];
+        }
+    } else if (NU > 1) {
+      ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+        ASLR_UNROLL for (int j = 0; j < NU; ++j) {
+          double s = 0.0;
+          ASLR_UNROLL for (int l = 0; l < NJ; ++l) s += dm.Binv[i * NJ + l] * m.S[l * NU + j];
+          kd->Fum[i][j] = s;
+        }
+    }
+    ASLR_UNROLL for (int i = 0; i < NX; ++i) { kd->Lx[i] = 0.0; kd->Lxxd[i] = 0.0; }
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) { kd->Lu[i] = 0.0; kd->Luud[i] = 0.0; }
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) kd->Lqq[i][j] = 0.0;
+  }
+
+  // ---- cost stack ----
+  double cost = 0.0;
+  for (int ci = 0; ci < m.ncosts; ++ci) {
+    const aslr_cost_t &ct = m.costs[ci];
+    const double w = ct.weight;
+    if (ct.type == ASLR_COST_FRAME_PLACEMENT) {
+      // oM(frame joint): the frame's joint index is runtime data; compose up to it
+      SE3d oMi[NJ];
+      oMi[0] = kin.liMi[0];
+      ASLR_UNROLL for (int i = 1; i < NJ; ++i) oMi[i] = se3_mul(oMi[i - 1], kin.liMi[i]);
+      const int fj = ct.frame_joint;
+      SE3d oMj = oMi[0];
+      ASLR_UNROLL for (int i = 1; i < NJ; ++i) if (i == fj) oMj = oMi[i];
+      const SE3d F = SE3d{m3(ct.frame_R), v3(ct.frame_p)};
+      const SE3d oMf = se3_mul(oMj, F);
+      const double *ref = frame_ref ? frame_ref : ct.ref;
+      const M3 Rr = m3(ref);
+      const V3 pr = v3(ref + 9);
+      SE3d rMf; // Mref^-1 * oMf
+      rMf.R = mulTN(Rr, oMf.R);
+      rMf.p = mulT(Rr, oMf.p - pr);
+      double r[6], theta;
+      V3 wlog;
+      log6(rMf, r, theta, wlog);
+      double a = 0.0;
+      ASLR_UNROLL for (int i = 0; i < 6; ++i) a += ct.act_w[i] * r[i] * r[i];
+      cost += w * 0.5 * a;
+      if (DIFF) {
+        M3 A, Bm;
+        jlog6(rMf, theta, wlog, A, Bm);
+        double Jr[6][NJ];
+        ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+          // fJf column j = (oMf^-1 oMj).act(S_j); zero for joints past the frame's joint
+          SE3d fMj;
+          fMj.R = mulTN(oMf.R, oMi[j].R);
+          fMj.p = mulT(oMf.R, oMi[j].p - oMf.p);
+          SV col = motion_act(fMj, SV{V3{0, 0, 0}, v3(c.axis[j])});
+          if (j > fj) col = sv_zero();
+          const V3 top = mul(A, col.lin) + mul(Bm, col.ang);
+          const V3 bot = mul(A, col.ang);
+          Jr[0][j] = top.x; Jr[1][j] = top.y; Jr[2][j] = top.z;
+          Jr[3][j] = bot.x; Jr[4][j] = bot.y; Jr[5][j] = bot.z;
+        }
+        ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+          double s = 0.0;
+          ASLR_UNROLL for (int i = 0; i < 6; ++i) s += Jr[i][j] * ct.act_w[i] * r[i];
+          kd->Lx[j] += w * s;
+          ASLR_UNROLL for (int l = 0; l < NJ; ++l) {
+            double hh = 0.0;
+            ASLR_UNROLL for (int i = 0; i < 6; ++i) hh += Jr[i][j] * ct.act_w[i] * Jr[i][l];
+            kd->Lqq[j][l] += w * hh;
+          }
+        }
+      }
+    } else if (ct.type == ASLR_COST_STATE) {
+      double a = 0.0;
+      ASLR_UNROLL for (int i = 0; i < NX; ++i) {
+        const double r = x[i] - ct.ref[i];
+        a += ct.act_w[i] * r * r;
+        if (DIFF) { kd->Lx[i] += w * ct.act_w[i] * r; kd->Lxxd[i] += w * ct.act_w[i]; }
+      }
+      cost += w * 0.5 * a;
+    } else if (ct.type == ASLR_COST_CONTROL) {
+      double a = 0.0;
+      ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+        const double r = u[i] - ct.ref[i];
+        a += ct.act_w[i] * r * r;
+        if (DIFF) { kd->Lu[i] += w * ct.act_w[i] * r; kd->Luud[i] += w * ct.act_w[i]; }
+      }
+      cost += w * 0.5 * a;
+    } else if (ct.type == ASLR_COST_PENDULUM) {
+      if (NJ >= 2) {
+        double s1, c1, s2, c2;
+        sincos(x[0], &s1, &c1);
+        sincos(x[NJ >= 2 ? 1 : 0], &s2, &c2);
+        const double r[6] = {s1, s2, 1.0 + c1, 1.0 + c2, x[NX > 4 ? 4 : 0], x[NX > 5 ? 5 : 0]};
+        const double *aw = ct.act_w;
+        double a = 0.0;
+        ASLR_UNROLL for (int i = 0; i < 6; ++i) a += aw[i] * r[i] * r[i];
+        cost += w * 0.5 * a;
+        if (DIFF) {
+          kd->Lx[0] += w * (c1 * aw[0] * r[0] - s1 * aw[2] * r[2]);
+          kd->Lx[NJ >= 2 ? 1 : 0] += w * (c2 * aw[1] * r[1] - s2 * aw[3] * r[3]);
+          kd->Lx[NX > 4 ? 4 : 0] += w * aw[4] * r[4];
+          kd->Lx[NX > 5 ? 5 : 0] += w * aw[5] * r[5];
+          kd->Lxxd[0] += w * ((c1 * c1 - s1 * s1) * aw[0] + (s1 * s1 + (1.0 - c1) * c1) * aw[2]);
+          kd->Lxxd[NJ >= 2 ? 1 : 0] += w * ((c2 * c2 - s2 * s2) * aw[1] + (s2 * s2 + (1.0 - c2) * c2) * aw[3]);
+          kd->Lxxd[NX > 4 ? 4 : 0] += w * aw[4];
+          kd->Lxxd[NX > 5 ? 5 : 0] += w * aw[5];
+        }
+      }
+    } else if (ct.type == ASLR_COST_STIFFNESS) {
+      constexpr int H = NU / 2;
+      double a = 0.0;
+      ASLR_UNROLL for (int i = 0; i < H; ++i) {
+        a += ct.lambda * (u[H + i] - ct.ref[i]);
+        if (DIFF) kd->Lu[H + i] += w * ct.lambda;
+      }
+      cost += w * a;
+    }
+  }
+  cost_out = cost;
+}
+
+// ---------------------------------------------------------------------------------------------
+// record element generator: element E (compile-time) of the DERIV record from the compact set.
+// Arithmetic order follows integrated_action.py:31-37.
+// ---------------------------------------------------------------------------------------------
+template <int NJ, int NU>
+struct RecLayout {
+  static constexpr int NX = 4 * NJ, NV = 2 * NJ;
+  static constexpr int oFx = 0, oFu = oFx + NX * NX, oLxx = oFu + NX * NU, oLxu = oLxx + NX * NX,
+                       oLuu = oLxu + NX * NU, oLx = oLuu + NU * NU, oLu = oLx + NX, oEnd = oLu + NU;
+  static constexpr int len = (oEnd + 15) / 16 * 16;
+};
+
+template <int NJ, int NU, int E>
+ASLR_DEV double rec_elem(const KnotDiff<NJ, NU> &k, double dt) {
+  using L = RecLayout<NJ, NU>;
+  constexpr int NX = L::NX, NV = L::NV;
+  if constexpr (E < L::oFu) {
+    constexpr int r = E / NX, cc = E % NX;
+    constexpr int ri = r % NV; // row of da_dx
+    double a; // da_dx[ri][cc]
+    if constexpr (ri < NJ) {
+      if constexpr (cc < NJ) a = k.Aqq[ri][cc];
+      else if constexpr (cc < 2 * NJ) a = k.Aqm[ri][cc - NJ];
+      else if constexpr (cc < 3 * NJ) a = k.Aqv[ri][cc - 2 * NJ];
+      else a = 0.0;
+    } else {
+      if constexpr (cc < NJ) a = k.Bk[ri - NJ][cc];
+      else if constexpr (cc < 2 * NJ) a = -k.Bk[ri - NJ][cc - NJ];
+      else a = 0.0;
+    }
+    double val;
+    if constexpr (r < NV) {
+      double top = a * dt;
+      if constexpr (cc == NV + r) top += 1.0;
+      val = dt * top;
+    } else {
+      val = dt * a;
+    }
+    if constexpr (r == cc) val += 1.0;
+    return val;
+  } else if constexpr (E < L::oLxx) {
+    constexpr int e = E - L::oFu, r = e / NU, cc = e % NU, ri = r % NV;
+    double a;
+    if constexpr (ri < NJ) a = k.Ful[ri][cc]; else a = k.Fum[ri - NJ][cc];
+    if constexpr (r < NV) return dt * (a * dt);
+    else return dt * a;
+  } else if constexpr (E < L::oLxu) {
+    constexpr int e = E - L::oLxx, r = e / NX, cc = e % NX;
+    double val = 0.0;
+    if constexpr (r < NJ && cc < NJ) val = k.Lqq[r][cc];
+    if constexpr (r == cc) val += k.Lxxd[r];
+    return val;
+  } else if constexpr (E < L::oLuu) {
+    return 0.0;
+  } else if constexpr (E < L::oLx) {
+    constexpr int e = E - L::oLuu, r = e / NU, cc = e % NU;
+    if constexpr (r == cc) return k.Luud[r]; else return 0.0;
+  } else if constexpr (E < L::oLu) {
+    return k.Lx[E - L::oLx];
+  } else if constexpr (E < L::oEnd) {
+    return k.Lu[E - L::oLu];
+  } else {
+    return 0.0;
+  }
+}
+
+// compile-time loop helper
+template <int I, int N, class F>
+ASLR_DEV void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+} // namespace aslr

@@ -1,0 +1,242 @@
+"""GPU engine: one shooting-problem shard on one MI355X, behind the C ABI of include/aslr_to_amd.h.
+
+PyTorch-ROCm is used for storage and streams only: ONE torch uint8 tensor is the workspace the HIP
+library carves into regions; every region is exposed as a zero-copy typed torch view.  All
+arithmetic happens in the hand-written HIP kernels (csrc/aslr_kernels.hip).  No CPU fallback: if the
+library or a GPU is missing this module raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from .lowering import lower_problem
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Engine(object):
+    """ShootingProblem shard resident in HBM.  Region layouts: include/aslr_to_amd.h."""
+
+    def __init__(self, lowered, device=None):
+        torch = _torch()
+        self.lib = _abi.load_library()
+        if not torch.cuda.is_available():
+            raise _abi.AslrError("aslr_to_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.low = lowered
+        self.B, self.T, self.nx, self.nu, self.rec = lowered.B, lowered.T, lowered.nx, lowered.nu, lowered.rec
+        nbytes = self.lib.aslr_workspace_bytes(C.byref(lowered.desc))
+        if nbytes <= 0:
+            raise _abi.AslrError("invalid problem description (aslr_workspace_bytes = %d)" % nbytes)
+        with torch.cuda.device(self.device):
+            self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            off = (-self.ws.data_ptr()) % 256
+            self.ws = self.ws[off:off + nbytes]
+            self.handle = C.c_void_p()
+            _abi.check(self.lib.aslr_problem_create(C.byref(lowered.desc), C.c_void_p(self.ws.data_ptr()),
+                                                    nbytes, self._stream(), C.byref(self.handle)),
+                       "aslr_problem_create")
+        self._views = {}
+
+    def _stream(self):
+        torch = _torch()
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.aslr_problem_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- zero-copy views of the workspace regions ----
+    def region(self, rid):
+        torch = _torch()
+        if rid in self._views:
+            return self._views[rid]
+        r = _abi.Region()
+        _abi.check(self.lib.aslr_problem_region(self.handle, rid, C.byref(r)), "aslr_problem_region")
+        raw = self.ws[r.offset:r.offset + r.bytes]
+        B, T, nx, nu, rec = self.B, self.T, self.nx, self.nu, self.rec
+        shapes = {
+            _abi.R_XS: (T + 1, B, nx), _abi.R_US: (T, B, nu), _abi.R_XNEXT: (T + 1, B, nx),
+            _abi.R_COST: (T + 1, B), _abi.R_DERIV: (T + 1, B, rec), _abi.R_GAPS: (T + 1, B, nx),
+            _abi.R_KGAIN: (T, B, nu, nx), _abi.R_KFF: (T, B, nu), _abi.R_QU: (T, B, nu),
+            _abi.R_VX: (T + 1, B, nx), _abi.R_VXX: (T + 1, B, nx, nx),
+            _abi.R_XS_TRY: (_abi.NALPHA, T + 1, B, nx), _abi.R_US_TRY: (_abi.NALPHA, T, B, nu),
+            _abi.R_TRAJ_F: (_abi.TF_COUNT, B), _abi.R_X0: (B, nx), _abi.R_FRAME_REF: (B, 12),
+            _abi.R_VXXF: (T + 1, B, nx),
+        }
+        if rid == _abi.R_TRAJ_I:
+            v = raw.view(torch.int32).view(_abi.TI_COUNT, B)
+        elif rid == _abi.R_NODE_MODEL:
+            v = raw.view(torch.int32)
+        elif rid in shapes:
+            v = raw.view(torch.float64).view(*shapes[rid])
+        else:
+            v = raw
+        self._views[rid] = v
+        return v
+
+    # batch-major views ([B, T, ...]) of the time-major storage
+    @property
+    def xs(self):
+        return self.region(_abi.R_XS).permute(1, 0, 2)
+
+    @property
+    def us(self):
+        return self.region(_abi.R_US).permute(1, 0, 2)
+
+    def deriv_block(self, name):
+        """[T+1, B, rows, cols] view of one block of the DERIV records."""
+        o = _abi.record_offsets(self.nx, self.nu)
+        nx, nu = self.nx, self.nu
+        shp = {"Fx": (nx, nx), "Fu": (nx, nu), "Lxx": (nx, nx), "Lxu": (nx, nu), "Luu": (nu, nu),
+               "Lx": (nx,), "Lu": (nu,)}[name]
+        n = int(np.prod(shp))
+        d = self.region(_abi.R_DERIV)
+        return d[:, :, o[name]:o[name] + n].reshape(self.T + 1, self.B, *shp)
+
+    def set_candidate(self, xs=None, us=None):
+        """xs: [B, T+1, nx] / [T+1, nx] / list of arrays; us likewise.  None -> zeros
+        (crocoddyl setCandidate with empty lists: state.zero() and zero controls)."""
+        torch = _torch()
+        X, U = self.region(_abi.R_XS), self.region(_abi.R_US)
+        if xs is None or (hasattr(xs, "__len__") and len(xs) == 0):
+            X.zero_()
+        else:
+            x = torch.as_tensor(np.asarray(xs, dtype=np.float64) if not torch.is_tensor(xs) else xs,
+                                dtype=torch.float64, device=self.device)
+            if x.dim() == 2:
+                x = x.unsqueeze(0).expand(self.B, -1, -1)
+            if tuple(x.shape) != (self.B, self.T + 1, self.nx):
+                raise ValueError("xs must have shape [B=%d, T+1=%d, nx=%d]" % (self.B, self.T + 1, self.nx))
+            X.copy_(x.permute(1, 0, 2))
+        if us is None or (hasattr(us, "__len__") and len(us) == 0):
+            U.zero_()
+        else:
+            u = torch.as_tensor(np.asarray(us, dtype=np.float64) if not torch.is_tensor(us) else us,
+                                dtype=torch.float64, device=self.device)
+            if u.dim() == 2:
+                u = u.unsqueeze(0).expand(self.B, -1, -1)
+            if tuple(u.shape) != (self.B, self.T, self.nu):
+                raise ValueError("us must have shape [B=%d, T=%d, nu=%d]" % (self.B, self.T, self.nu))
+            U.copy_(u.permute(1, 0, 2))
+
+    # ---- the hot path ----
+    def calc(self):
+        _abi.check(self.lib.aslr_calc(self.handle, self._stream()), "aslr_calc")
+
+    def calc_diff(self):
+        _abi.check(self.lib.aslr_calc_diff(self.handle, self._stream()), "aslr_calc_diff")
+
+    def backward_pass(self, sp):
+        _abi.check(self.lib.aslr_backward_pass(self.handle, C.byref(sp), self._stream()), "aslr_backward_pass")
+
+    def forward_pass(self, sp):
+        _abi.check(self.lib.aslr_forward_pass(self.handle, C.byref(sp), self._stream()), "aslr_forward_pass")
+
+    def iterate(self, sp, first):
+        _abi.check(self.lib.aslr_iterate(self.handle, C.byref(sp), 1 if first else 0, self._stream()), "aslr_iterate")
+
+    def finalize(self):
+        _abi.check(self.lib.aslr_finalize(self.handle, self._stream()), "aslr_finalize")
+
+    def count_active(self):
+        n = C.c_int32(0)
+        _abi.check(self.lib.aslr_count_active(self.handle, self._stream(), C.byref(n)), "aslr_count_active")
+        return n.value
+
+    def solve(self, sp, poll_every=4):
+        it = C.c_int32(0)
+        _abi.check(self.lib.aslr_solve(self.handle, C.byref(sp), poll_every, self._stream(), C.byref(it)), "aslr_solve")
+        return it.value
+
+    def traj_f(self, row):
+        return self.region(_abi.R_TRAJ_F)[row]
+
+    def traj_i(self, row):
+        return self.region(_abi.R_TRAJ_I)[row]
+
+    def dam_eval(self, model_index, x, u):
+        """DAM-level calc + calcDiff on n points (numpy in / numpy out)."""
+        torch = _torch()
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        u = np.atleast_2d(np.asarray(u, dtype=np.float64))
+        n, nx, nu, nv = x.shape[0], self.nx, self.nu, self.nx // 2
+        dx = torch.as_tensor(x, device=self.device).contiguous()
+        du = torch.as_tensor(u, device=self.device).contiguous()
+        outs = {"xout": (n, nv), "cost": (n,), "Fx": (n, nv, nx), "Fu": (n, nv, nu), "Lx": (n, nx), "Lu": (n, nu),
+                "Lxx": (n, nx, nx), "Lxu": (n, nx, nu), "Luu": (n, nu, nu)}
+        t = {k: torch.empty(s, dtype=torch.float64, device=self.device) for k, s in outs.items()}
+        p = lambda k: C.c_void_p(t[k].data_ptr())
+        _abi.check(self.lib.aslr_dam_eval(self.handle, model_index, n, C.c_void_p(dx.data_ptr()),
+                                          C.c_void_p(du.data_ptr()), p("xout"), p("cost"), p("Fx"), p("Fu"),
+                                          p("Lx"), p("Lu"), p("Lxx"), p("Lxu"), p("Luu"), self._stream()),
+                   "aslr_dam_eval")
+        return {k: v.cpu().numpy() for k, v in t.items()}
+
+
+class _PointEvaluator(object):
+    """B = 1, T = 1 problem around one action model: backs `model.calc(data, x, u)`."""
+
+    def __init__(self, model):
+        from .models import IntegratedActionModelEulerASR
+        if isinstance(model, IntegratedActionModelEulerASR):
+            self.iam = model
+        else:
+            self.iam = IntegratedActionModelEulerASR(model, 0.0)
+        self._sig = None
+        self.engine = None
+
+    def _ensure(self):
+        # re-lower when the user mutated the model (weights, bounds, dt ...) since the last call
+        low = lower_problem(np.zeros(self.iam.state.nx), [self.iam], self.iam)
+        sig = bytes(memoryview(low.desc.models[0])) + bytes(memoryview(low.desc.chain))
+        if sig != self._sig:
+            if self.engine is not None:
+                self.engine.close()
+            self.engine = Engine(low)
+            self._sig = sig
+        return self.engine
+
+    def dam(self, data, x, u, diff):
+        e = self._ensure()
+        r = e.dam_eval(0, x, u)
+        data.xout[:] = r["xout"][0]
+        data.cost = float(r["cost"][0])
+        if diff:
+            for k in ("Fx", "Fu", "Lx", "Lu", "Lxx", "Lxu", "Luu"):
+                getattr(data, k)[...] = r[k][0]
+
+    def integrated(self, data, x, u, diff):
+        torch = _torch()
+        e = self._ensure()
+        x = np.asarray(x, dtype=np.float64)
+        if u is None:
+            u = self.iam.differential._default_u()
+        xs = np.stack([x, x])[None]
+        e.set_candidate(xs, np.asarray(u, dtype=np.float64)[None, None])
+        (e.calc_diff if diff else e.calc)()
+        torch.cuda.synchronize(e.device)
+        data.xnext[:] = e.region(_abi.R_XNEXT)[0, 0].cpu().numpy()
+        data.cost = float(e.region(_abi.R_COST)[0, 0].item())
+        data.dx[:] = data.xnext - x
+        if diff:
+            for k in ("Fx", "Fu", "Lx", "Lu", "Lxx", "Lxu", "Luu"):
+                getattr(data, k)[...] = e.deriv_block(k)[0, 0].cpu().numpy()
+
+
+def point_evaluator(model):
+    if getattr(model, "_evaluator", None) is None:
+        model._evaluator = _PointEvaluator(model)
+    return model._evaluator

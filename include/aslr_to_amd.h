@@ -1,0 +1,281 @@
+/*
+ * aslr_to_amd.h -- C ABI of the MI355X-native batched DDP / FDDP / BoxDDP hot path
+ *                  for aslr_to's soft-actuator (SEA / VSA) free-forward-dynamics models.
+ *
+ * The reference (spykspeigel/aslr_to) has no FFI of its own: its hot path sits behind
+ * Crocoddyl's Python class protocol (Boost.Python bindings of C++ abstract classes).
+ * This header is the C ABI that the Python layer `aslr_to_amd` binds with ctypes, and that a
+ * reference maintainer would bind in place of the per-knot Python callbacks
+ * (see INTEGRATION.md).  Every entry point cites the reference interface it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C types only: int32_t, double, raw pointers; no torch / C++ types;
+ *   - all arithmetic is IEEE float64 (dtype "f64");
+ *   - every function returns int: 0 = ok, <0 = error (see ASLR_E_*); no exceptions cross
+ *     the ABI.  Numerical events (Cholesky failure, NaN, reg at max, not converged) are
+ *     NOT errors: they are per-trajectory status bits (ASLR_ST_*), mirroring Crocoddyl's
+ *     catch-and-regularise behaviour and its `solve -> bool`;
+ *   - the caller owns every buffer.  The library owns only the opaque handle; the device
+ *     workspace is ONE caller-allocated buffer (a torch tensor) that the library carves into
+ *     named regions (aslr_region);
+ *   - kernels are enqueued on the caller's hipStream_t (passed as void*); nothing in the
+ *     data path calls hipDeviceSynchronize or allocates.
+ *
+ * State layout (python/aslr_to/statemultibody_aslr.py:7-11): x = [q_l, q_m, v_l, v_m],
+ * nx = ndx = 4*nj for the revolute chains of every BASELINE config; nu = nj (SEA) or 2*nj (VSA).
+ */
+#ifndef ASLR_TO_AMD_H
+#define ASLR_TO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASLR_ABI_VERSION 1
+
+#define ASLR_MAX_NJ     7   /* link-side DoF (2-DoF arm, 7-DoF arm)          */
+#define ASLR_MAX_NX     28  /* 4 * ASLR_MAX_NJ                                */
+#define ASLR_MAX_NU     14  /* 2 * ASLR_MAX_NJ (VSA)                          */
+#define ASLR_MAX_COSTS  6   /* cost terms per CostModelSum                    */
+#define ASLR_MAX_MODELS 4   /* distinct action models per shooting problem    */
+#define ASLR_NALPHA     10  /* Crocoddyl line-search step lengths 2^-j, j<10  */
+
+/* error codes */
+#define ASLR_OK            0
+#define ASLR_E_INVALID    -1  /* bad argument / unsupported size combination */
+#define ASLR_E_HIP        -2  /* a HIP runtime call failed                   */
+#define ASLR_E_NODEVICE   -3  /* no GPU visible                              */
+#define ASLR_E_WORKSPACE  -4  /* workspace too small / misaligned            */
+
+/* differential action model kind */
+#define ASLR_DAM_SEA 0 /* DifferentialFreeASRFwdDynamicsModel (python/aslr_to/free_fwddyn_asr.py:6)  */
+#define ASLR_DAM_VSA 1 /* DifferentialFreeFwdDynamicsModelVSA (python/aslr_to/free_fwddyn_vsa.py:6) */
+
+/* cost term kind */
+#define ASLR_COST_FRAME_PLACEMENT 0 /* CostModelResidual(ResidualModelFramePlacementASR) (python/aslr_to/residual_frame_placement.py:7) */
+#define ASLR_COST_STATE           1 /* CostModelResidual(ResidualModelState)   (examples/two_dof_vsa_boxddp.py:30-31) */
+#define ASLR_COST_CONTROL         2 /* CostModelResidual(ResidualModelControl) (examples/two_dof_vsa_boxddp.py:33-34) */
+#define ASLR_COST_PENDULUM        3 /* CostModelDoublePendulum (python/aslr_to/__init__.py:223-259) */
+#define ASLR_COST_STIFFNESS       4 /* CostModelStiffness (python/aslr_to/stiffness_cost.py:6-22)   */
+
+/* solver kind */
+#define ASLR_SOLVER_DDP    0 /* crocoddyl.SolverDDP    (north_star)                        */
+#define ASLR_SOLVER_FDDP   1 /* crocoddyl.SolverFDDP   (examples/two_dof_sea.py:69)        */
+#define ASLR_SOLVER_BOXDDP 2 /* crocoddyl.SolverBoxDDP (examples/two_dof_vsa_boxddp.py:69) */
+
+/* per-trajectory status bits */
+#define ASLR_ST_CONVERGED   1  /* was_feasible && stop < th_stop  -> solve() returned true  */
+#define ASLR_ST_REG_MAX     2  /* regularisation hit reg_max      -> solve() returned false */
+#define ASLR_ST_BACKWARD_ERR 4 /* at least one Cholesky failure / NaN in a backward pass (recovered by regularisation) */
+#define ASLR_ST_FORWARD_ERR 8  /* at least one line-search trial produced NaN/Inf (that alpha was skipped)             */
+
+/* Fixed-base serial chain of revolute joints (stands in for pinocchio.Model; the URDFs of
+ * example_robot_data are unobtainable offline, see robots.py).  Joint j's parent is joint j-1
+ * (the base for j = 0).  Pinocchio conventions: joint_R/joint_p = placement of the joint frame
+ * in its parent joint frame at q = 0; inertia = rotational inertia about the COM, expressed in
+ * the joint frame; com = lever of the COM in the joint frame. */
+typedef struct aslr_chain {
+  int32_t nj;
+  int32_t _pad0;
+  double gravity[3];                 /* model.gravity.linear (examples/two_dof_sea.py:20) */
+  double joint_R[ASLR_MAX_NJ][9];    /* row-major 3x3 */
+  double joint_p[ASLR_MAX_NJ][3];
+  double axis[ASLR_MAX_NJ][3];       /* unit rotation axis in the joint frame */
+  double mass[ASLR_MAX_NJ];
+  double com[ASLR_MAX_NJ][3];
+  double inertia[ASLR_MAX_NJ][9];    /* row-major symmetric 3x3 */
+} aslr_chain_t;
+
+/* One entry of a CostModelSum (examples/two_dof_vsa_boxddp.py:40-48). */
+typedef struct aslr_cost {
+  int32_t type;                      /* ASLR_COST_*                                          */
+  int32_t frame_joint;               /* FRAME_PLACEMENT: joint the frame is attached to      */
+  double weight;                     /* addCost(name, cost, weight)                          */
+  double act_w[ASLR_MAX_NX];         /* ActivationModelWeightedQuad weights (ones for Quad)  */
+  double ref[ASLR_MAX_NX];           /* STATE: xref; CONTROL: uref; STIFFNESS: Kref;
+                                        FRAME_PLACEMENT: reference placement R[9] (row-major), p[3] */
+  double frame_R[9];                 /* FRAME_PLACEMENT: frame placement on frame_joint      */
+  double frame_p[3];
+  double lambda;                     /* STIFFNESS: lamda (python/aslr_to/stiffness_cost.py:11) */
+} aslr_cost_t;
+
+/* One IntegratedActionModelEulerASR(differential, dt) (python/aslr_to/integrated_action.py:6). */
+typedef struct aslr_model {
+  int32_t dam;                       /* ASLR_DAM_*                                           */
+  int32_t nu;                        /* SEA: nj ; VSA: 2*nj                                   */
+  int32_t ncosts;
+  int32_t has_u_limits;              /* u_lb/u_ub assigned (examples/two_dof_vsa_boxddp.py:59-60) */
+  double dt;                         /* 0 for the terminal model (examples/two_dof_sea.py:57-58) */
+  double K[ASLR_MAX_NJ * ASLR_MAX_NJ];   /* SEA spring stiffness, row-major nj x nj            */
+  double B[ASLR_MAX_NJ * ASLR_MAX_NJ];   /* motor inertia, row-major nj x nj                    */
+  double S[ASLR_MAX_NJ * ASLR_MAX_NJ];   /* SEA: motor rows of dtau_du (nj x nu): tau_m = S u.
+                                            Identity for ASRActuation; selector for
+                                            ActuationModelDoublePendulum (python/aslr_to/__init__.py:262-290) */
+  double u_lb[ASLR_MAX_NU];
+  double u_ub[ASLR_MAX_NU];
+  aslr_cost_t costs[ASLR_MAX_COSTS];
+} aslr_model_t;
+
+/* crocoddyl.ShootingProblem(x0, runningModels, terminalModel), batched over B trajectories that
+ * share structure (examples/two_dof_vsa_boxddp.py:66).  Pointers are HOST pointers, read during
+ * create only. */
+typedef struct aslr_problem_desc {
+  int32_t B;                         /* trajectories in this shard                           */
+  int32_t T;                         /* running knots                                        */
+  int32_t nmodels;
+  int32_t _pad0;
+  aslr_chain_t chain;
+  aslr_model_t models[ASLR_MAX_MODELS];
+  const int32_t *node_model;         /* [T+1] model index per node; node T is the terminal   */
+  const double *x0;                  /* [B][nx]                                              */
+  const double *frame_ref;           /* optional [B][12] per-trajectory reference placement
+                                        (R row-major, p) overriding every FRAME_PLACEMENT ref */
+} aslr_problem_desc_t;
+
+/* Solver parameters: crocoddyl.SolverDDP/FDDP/BoxDDP members. */
+typedef struct aslr_solver_params {
+  int32_t solver;                    /* ASLR_SOLVER_*                                        */
+  int32_t maxiter;
+  int32_t is_feasible;               /* solve(..., isFeasible)                               */
+  int32_t fixed_iterations;          /* 1: never stop on convergence (throughput benchmarking) */
+  double reg_init;                   /* NaN -> reg_min                                       */
+  double th_stop;                    /* 1e-9 (examples set 1e-7)                             */
+  double th_grad;                    /* 1e-12 */
+  double th_gaptol;                  /* 1e-16 */
+  double th_stepdec;                 /* 0.5   */
+  double th_stepinc;                 /* 0.01  */
+  double th_acceptstep;              /* 0.1   */
+  double th_acceptnegstep;           /* 2 (FDDP) */
+  double reg_min;                    /* 1e-9  */
+  double reg_max;                    /* 1e9   */
+  double reg_incfactor;              /* 10    */
+  double reg_decfactor;              /* 10    */
+  int32_t boxqp_maxiter;             /* 100   */
+  int32_t _pad0;
+  double boxqp_th_acceptstep;        /* 0.1   */
+  double boxqp_th_grad;              /* 1e-9  */
+  double boxqp_reg;                  /* 1e-9  */
+} aslr_solver_params_t;
+
+/* Named regions of the device workspace.  Layouts (doubles unless noted), time-major so that a
+ * wavefront's accesses to consecutive trajectories coalesce:
+ *   XS      [T+1][B][nx]        candidate states      (solver.xs)
+ *   US      [T][B][nu]          candidate controls    (solver.us)
+ *   XNEXT   [T+1][B][nx]        data.xnext per node
+ *   COST    [T+1][B]            data.cost per node
+ *   DERIV   [T+1][B][rec]       per-knot record  Fx(nx*nx) Fu(nx*nu) Lxx(nx*nx) Lxu(nx*nu)
+ *                               Luu(nu*nu) Lx(nx) Lu(nu), row-major blocks, rec padded to 16 doubles
+ *   GAPS    [T+1][B][nx]        fs
+ *   KGAIN   [T][B][nu*nx]       solver.K (row-major nu x nx)
+ *   KFF     [T][B][nu]          solver.k
+ *   QU      [T][B][nu]          solver.Qu
+ *   VX      [T+1][B][nx]        solver.Vx
+ *   VXX     [T+1][B][nx*nx]     solver.Vxx
+ *   XS_TRY  [NALPHA][T+1][B][nx]  line-search candidates
+ *   US_TRY  [NALPHA][T][B][nu]
+ *   VXXF    [T+1][B][nx]        Vxx[t] fs[t] (FDDP expected improvement)
+ *   TRAJ_F  [ASLR_TF_COUNT][B]  per-trajectory doubles (ASLR_TF_*)
+ *   TRAJ_I  [ASLR_TI_COUNT][B]  per-trajectory int32   (ASLR_TI_*)
+ */
+enum aslr_region_id {
+  ASLR_R_XS = 0, ASLR_R_US, ASLR_R_XNEXT, ASLR_R_COST, ASLR_R_DERIV, ASLR_R_GAPS,
+  ASLR_R_KGAIN, ASLR_R_KFF, ASLR_R_QU, ASLR_R_VX, ASLR_R_VXX, ASLR_R_XS_TRY, ASLR_R_US_TRY,
+  ASLR_R_TRAJ_F, ASLR_R_TRAJ_I, ASLR_R_X0, ASLR_R_FRAME_REF, ASLR_R_VXXF, ASLR_R_DESC,
+  ASLR_R_NODE_MODEL, ASLR_R_COUNT
+};
+
+/* rows of TRAJ_F */
+enum {
+  ASLR_TF_COST = 0, ASLR_TF_STOP, ASLR_TF_XREG, ASLR_TF_D1, ASLR_TF_D2, ASLR_TF_STEP,
+  ASLR_TF_DV, ASLR_TF_DVEXP, ASLR_TF_DG, ASLR_TF_DQ, ASLR_TF_COST_TRY0 /* ..+NALPHA */,
+  ASLR_TF_DVTRY0 = ASLR_TF_COST_TRY0 + ASLR_NALPHA /* FDDP dv per alpha, ..+NALPHA */,
+  ASLR_TF_COUNT = ASLR_TF_DVTRY0 + ASLR_NALPHA
+};
+/* rows of TRAJ_I */
+enum {
+  ASLR_TI_ITER = 0, ASLR_TI_STATUS, ASLR_TI_FEASIBLE, ASLR_TI_WAS_FEASIBLE, ASLR_TI_RECALC,
+  ASLR_TI_ACCEPTED /* index of accepted alpha, -1 none */, ASLR_TI_DONE, ASLR_TI_NTRIALS,
+  ASLR_TI_GAPFLAG /* some |gap| >= th_gaptol seen by the last calcDiff sweep */,
+  ASLR_TI_COUNT
+};
+
+typedef struct aslr_region {
+  int64_t offset;                    /* in bytes from the workspace base                     */
+  int64_t bytes;
+} aslr_region_t;
+
+typedef struct aslr_problem aslr_problem_t; /* opaque */
+
+/* ---- ABI self-description (callable without a GPU) ------------------------------------ */
+int aslr_abi_version(void);
+/* sizeof() of the POD structs above as compiled, so a binding can check its mirror:
+ * which = 0 chain, 1 cost, 2 model, 3 problem_desc, 4 solver_params, 5 region */
+int64_t aslr_sizeof(int which);
+/* record length in doubles (padded) for given nx, nu */
+int32_t aslr_record_len(int32_t nx, int32_t nu);
+/* fill defaults of crocoddyl.SolverDDP */
+void aslr_solver_params_default(aslr_solver_params_t *p, int32_t solver);
+/* workspace bytes needed by a problem of this description (no GPU needed) */
+int64_t aslr_workspace_bytes(const aslr_problem_desc_t *desc);
+
+/* ---- problem handle -------------------------------------------------------------------- */
+/* Replaces crocoddyl.ShootingProblem(x0, [runningModel]*T, terminalModel)
+ * (examples/two_dof_vsa_boxddp.py:66) for B trajectories.  `workspace` is a device buffer of at
+ * least aslr_workspace_bytes(desc) bytes, 256-byte aligned, owned by the caller and kept alive
+ * until destroy.  Uploads the description, x0 and frame_ref on `stream`. */
+int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_t workspace_bytes,
+                        void *stream, aslr_problem_t **out);
+int aslr_problem_destroy(aslr_problem_t *p);
+int aslr_problem_region(const aslr_problem_t *p, int32_t region_id, aslr_region_t *out);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+/* ShootingProblem.calc(xs, us): IntegratedActionModelEulerASR.calc on every node
+ * (python/aslr_to/integrated_action.py:13-26 -> free_fwddyn_asr.py:20-56 / free_fwddyn_vsa.py:20-57).
+ * Reads XS, US; writes XNEXT, COST. */
+int aslr_calc(aslr_problem_t *p, void *stream);
+/* ShootingProblem.calcDiff(xs, us) (+ the calc it relies on): integrated_action.py:28-42 ->
+ * free_fwddyn_asr.py:58-92 / free_fwddyn_vsa.py:59-94, residual_frame_placement.py:17-24.
+ * Reads XS, US; writes XNEXT, COST, DERIV. */
+int aslr_calc_diff(aslr_problem_t *p, void *stream);
+/* SolverDDP.backwardPass / SolverBoxDDP.computeGains at regularisation
+ * TRAJ_F[XREG] with gaps GAPS (used when TRAJ_I[FEASIBLE] == 0).  Reads DERIV, GAPS, US, KFF;
+ * writes KGAIN, KFF, QU, VX, VXX, TRAJ_F[D1,D2,STOP,DG,DQ], TRAJ_I[STATUS]. */
+int aslr_backward_pass(aslr_problem_t *p, const aslr_solver_params_t *sp, void *stream);
+/* SolverDDP/FDDP/BoxDDP.forwardPass for all ASLR_NALPHA step lengths.
+ * Reads XS, US, KGAIN, KFF, GAPS; writes XS_TRY, US_TRY, TRAJ_F[COST_TRY0..]. */
+int aslr_forward_pass(aslr_problem_t *p, const aslr_solver_params_t *sp, void *stream);
+/* solver.solve(init_xs, init_us, maxiter, isFeasible, regInit) (examples/two_dof_vsa_boxddp.py:81):
+ * XS/US hold the warm start on entry and the solution on exit; TRAJ_F/TRAJ_I the per-trajectory
+ * cost / stop / iter / status.  Enqueues everything on `stream`; `iters_done` (host, optional)
+ * receives the number of lock-step batch iterations launched.  If sp->fixed_iterations == 0 the
+ * host polls the active-trajectory count every `poll_every` iterations (one 4-byte D2H). */
+int aslr_solve(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t poll_every,
+               void *stream, int32_t *iters_done);
+/* one lock-step DDP iteration (calcDiff sweep + backward pass + line search), the unit the
+ * benchmark's "step" times.  `first` != 0 re-initialises the per-trajectory solver state. */
+int aslr_iterate(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream);
+/* commit the last accepted line-search candidate into XS/US (called by aslr_solve on exit). */
+int aslr_finalize(aslr_problem_t *p, void *stream);
+/* number of trajectories neither converged nor failed; synchronises `stream`. */
+int aslr_count_active(aslr_problem_t *p, void *stream, int32_t *active);
+
+/* DifferentialFree{ASR,VSA}FwdDynamicsModel.calc + calcDiff on `n` arbitrary points with model
+ * `model_index` of the problem (the path the reference's unit tests exercise:
+ * unittest/test_vsa_freefwddyn.py:26-38).  All pointers are DEVICE pointers; x [n][nx], u [n][nu];
+ * outputs (row-major, any may be NULL): xout [n][2nj], cost [n], Fx [n][2nj*nx], Fu [n][2nj*nu],
+ * Lx [n][nx], Lu [n][nu], Lxx [n][nx*nx], Lxu [n][nx*nu], Luu [n][nu*nu].  Trajectory 0's
+ * frame_ref override (if any) applies. */
+int aslr_dam_eval(aslr_problem_t *p, int32_t model_index, int32_t n, const double *x,
+                  const double *u, double *xout, double *cost, double *Fx, double *Fu, double *Lx,
+                  double *Lu, double *Lxx, double *Lxu, double *Luu, void *stream);
+
+/* last HIP error string of this thread (static storage) */
+const char *aslr_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASLR_TO_AMD_H */

@@ -1,0 +1,179 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Float64 throughout; tolerances are written at each assert.
+
+north_star tolerance for solver results: 1e-6 on xs/us, 1e-4 on final cost.  Per-kernel outputs are
+held to ~1e-9 relative (they differ from the oracle only by FMA contraction / libm rounding).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from aslr_to_amd import _abi, scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(low):
+    from aslr_to_amd.engine import Engine
+    return Engine(low)
+
+
+def _sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.max(np.abs(a - b) / (1.0 + np.abs(b))) if a.size else 0.0
+
+
+CASES = [("two_dof_vsa_boxddp", dict(B=70, T=5)), ("two_dof_sea", dict(B=70, T=5)),
+         ("double_pendulum", dict(T=6)), ("talos_arm_sea", dict(B=5, T=3))]
+
+
+def _random_candidate(low, seed):
+    rng = np.random.default_rng(seed)
+    xs = rng.uniform(-0.8, 0.8, (low.T + 1, low.B, low.nx))
+    us = rng.uniform(-1.0, 1.0, (low.T, low.B, low.nu))
+    if low.dam == _abi.DAM_VSA:
+        us[..., low.nu // 2:] = rng.uniform(0.1, 5.0, (low.T, low.B, low.nu // 2))
+    return xs, us
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+def test_calc_and_calcdiff_match_oracle(oracle, name, kw):
+    import torch
+    sc = scenarios.SCENARIOS[name](**kw)
+    low = scenarios.lower(sc)
+    e = _engine(low)
+    xs, us = _random_candidate(low, 1)
+    e.region(_abi.R_XS).copy_(torch.as_tensor(xs))
+    e.region(_abi.R_US).copy_(torch.as_tensor(us))
+    e.calc_diff()
+    _sync()
+    xnext, cost, deriv = oracle.calc_diff(low, xs, us)
+    assert _relerr(_np(e.region(_abi.R_XNEXT)), xnext) < 1e-11
+    assert _relerr(_np(e.region(_abi.R_COST)), cost) < 1e-11
+    g = _np(e.region(_abi.R_DERIV))
+    err = _relerr(g, deriv)
+    assert err < 1e-9, "DERIV record mismatch %g" % err
+    # calc alone writes the same xnext / cost
+    e.region(_abi.R_XNEXT).zero_()
+    e.region(_abi.R_COST).zero_()
+    e.calc()
+    _sync()
+    assert _relerr(_np(e.region(_abi.R_XNEXT)), xnext) < 1e-11
+    assert _relerr(_np(e.region(_abi.R_COST)), cost) < 1e-11
+
+
+def _backward_inputs(oracle, low, seed):
+    xs, us = _random_candidate(low, seed)
+    _, _, deriv = oracle.calc_diff(low, xs, us)
+    rng = np.random.default_rng(seed + 7)
+    gaps = rng.uniform(-0.05, 0.05, (low.T + 1, low.B, low.nx))
+    return xs, us, deriv, gaps
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+@pytest.mark.parametrize("feasible", [0, 1])
+@pytest.mark.parametrize("hs", [1, 2])
+def test_backward_pass_matches_oracle(oracle, monkeypatch, name, kw, feasible, hs):
+    import torch
+    monkeypatch.setenv("ASLR_BWD_HS", str(hs))
+    sc = scenarios.SCENARIOS[name](**kw)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc)
+    e = _engine(low)
+    xs, us, deriv, gaps = _backward_inputs(oracle, low, 3)
+    xreg = 1e-3
+    e.region(_abi.R_US).copy_(torch.as_tensor(us))
+    e.region(_abi.R_DERIV).copy_(torch.as_tensor(deriv))
+    e.region(_abi.R_GAPS).copy_(torch.as_tensor(gaps))
+    e.region(_abi.R_KFF).zero_()
+    e.region(_abi.R_TRAJ_F)[_abi.TF_XREG].fill_(xreg)
+    e.region(_abi.R_TRAJ_I)[_abi.TI_FEASIBLE].fill_(feasible)
+    e.region(_abi.R_TRAJ_I)[_abi.TI_STATUS].fill_(0)
+    e.backward_pass(sp)
+    _sync()
+    ref = oracle.backward_pass(low, sp, deriv, gaps, us, xreg, feasible)
+    assert not ref["fail"].any()
+    assert (_np(e.traj_i(_abi.TI_STATUS)) & _abi.ST_BACKWARD_ERR == 0).all()
+    tol = 1e-8
+    assert _relerr(_np(e.region(_abi.R_KGAIN)), ref["K"]) < tol
+    assert _relerr(_np(e.region(_abi.R_KFF)), ref["k"]) < tol
+    assert _relerr(_np(e.region(_abi.R_QU)), ref["Qu"]) < tol
+    assert _relerr(_np(e.region(_abi.R_VX)), ref["Vx"]) < tol
+    assert _relerr(_np(e.region(_abi.R_VXX)), ref["Vxx"]) < tol
+    assert _relerr(_np(e.traj_f(_abi.TF_D1)), ref["d1"]) < tol
+    assert _relerr(_np(e.traj_f(_abi.TF_D2)), ref["d2"]) < tol
+    assert _relerr(_np(e.traj_f(_abi.TF_STOP)), ref["stop"]) < tol
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+def test_forward_pass_matches_oracle_for_every_alpha(oracle, name, kw):
+    import torch
+    sc = scenarios.SCENARIOS[name](**kw)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc)
+    e = _engine(low)
+    xs, us, deriv, gaps = _backward_inputs(oracle, low, 5)
+    ref_b = oracle.backward_pass(low, sp, deriv, gaps, us, 1e-3, 1)
+    K, k = 0.05 * ref_b["K"], 0.05 * ref_b["k"]  # mild gains keep every alpha's rollout finite
+    e.region(_abi.R_XS).copy_(torch.as_tensor(xs))
+    e.region(_abi.R_US).copy_(torch.as_tensor(us))
+    e.region(_abi.R_KGAIN).copy_(torch.as_tensor(K))
+    e.region(_abi.R_KFF).copy_(torch.as_tensor(k))
+    e.region(_abi.R_TRAJ_I)[_abi.TI_FEASIBLE].fill_(1)
+    e.forward_pass(sp)
+    _sync()
+    XT, UT = _np(e.region(_abi.R_XS_TRY)), _np(e.region(_abi.R_US_TRY))
+    for a in range(_abi.NALPHA):
+        xs_try, us_try, cost_try, fail = oracle.forward_pass(low, sp, 0.5 ** a, xs, us, K, k)
+        ok = fail == 0
+        assert ok.any()
+        assert _relerr(XT[a][:, ok], xs_try[:, ok]) < 1e-9
+        assert _relerr(UT[a][:, ok], us_try[:, ok]) < 1e-9
+        got = _np(e.traj_f(_abi.TF_COST_TRY0 + a))
+        assert _relerr(got[ok], cost_try[ok]) < 1e-9
+        assert np.isnan(got[~ok]).all()
+
+
+SOLVE_CASES = [
+    ("two_dof_vsa_boxddp", dict(B=12, T=100), "SolverBoxDDP"),
+    ("two_dof_sea", dict(B=12, T=100), "SolverDDP"),
+    ("two_dof_sea", dict(B=6, T=100), "SolverFDDP"),
+    ("double_pendulum", dict(T=10), "SolverDDP"),
+    ("double_pendulum", dict(T=10), "SolverFDDP"),
+]
+
+
+@pytest.mark.parametrize("name,kw,solver", SOLVE_CASES)
+def test_solve_matches_oracle(oracle, name, kw, solver):
+    """north_star: xs/us within 1e-6, final cost within 1e-4 of the CPU solver on identical inputs."""
+    sc = scenarios.SCENARIOS[name](**kw)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc, solver=solver)
+    ref = oracle.solve(low, sp)
+    e = _engine(low)
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=4)
+    _sync()
+    it_g, it_r = _np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER]
+    st_g, st_r = _np(e.traj_i(_abi.TI_STATUS)), ref["traj_i"][_abi.TI_STATUS]
+    conv = (st_r & _abi.ST_CONVERGED) != 0
+    assert conv.any()
+    assert ((st_g & _abi.ST_CONVERGED) != 0)[conv].all()
+    X, U = _np(e.region(_abi.R_XS)), _np(e.region(_abi.R_US))
+    dx = np.abs(X - ref["xs"])[:, conv].max()
+    du = np.abs(U - ref["us"])[:, conv].max()
+    dc = np.abs(_np(e.traj_f(_abi.TF_COST)) - ref["traj_f"][_abi.TF_COST])[conv].max()
+    print(name, solver, "iters gpu", it_g, "oracle", it_r, "dx %.2e du %.2e dcost %.2e" % (dx, du, dc))
+    assert dx < 1e-6 and du < 1e-6, (dx, du)
+    assert dc < 1e-4, dc
+    assert (it_g == it_r)[conv].all()
