@@ -96,8 +96,8 @@ def default_solver_params(solver=SOLVER_DDP):
     sp.reg_decfactor = 10.0
     sp.boxqp_maxiter = 100
     sp.boxqp_th_acceptstep = 0.1
-    sp.boxqp_th_grad = 1e-9
-    sp.boxqp_reg = 1e-9
+    sp.boxqp_th_grad = 1e-5
+    sp.boxqp_reg = 0.0
     return sp
 
 
@@ -132,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "aslr_abi_version", "aslr_sizeof", "aslr_record_len", "aslr_solver_params_default",
     "aslr_workspace_bytes", "aslr_problem_create", "aslr_problem_destroy", "aslr_problem_region",
     "aslr_calc", "aslr_calc_diff", "aslr_backward_pass", "aslr_forward_pass", "aslr_solve",
-    "aslr_iterate", "aslr_finalize", "aslr_count_active", "aslr_dam_eval", "aslr_last_error",
+    "aslr_iterate", "aslr_iterate_timed", "aslr_finalize", "aslr_count_active", "aslr_dam_eval", "aslr_last_error",
 ]
 
 
@@ -147,6 +147,9 @@ def load_library():
             "aslr_to_amd: the HIP extension %s is missing. Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback." % path)
+    # torch first: its bundled HIP runtime must be the one (and only) libamdhip64 in the process, or
+    # device pointers of torch tensors would belong to a different runtime than our kernel launches
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.aslr_abi_version.restype = C.c_int
@@ -176,6 +179,8 @@ def load_library():
     lib.aslr_solve.argtypes = [vp, C.POINTER(SolverParams), i32, vp, C.POINTER(i32)]
     lib.aslr_iterate.restype = C.c_int
     lib.aslr_iterate.argtypes = [vp, C.POINTER(SolverParams), i32, vp]
+    lib.aslr_iterate_timed.restype = C.c_int
+    lib.aslr_iterate_timed.argtypes = [vp, C.POINTER(SolverParams), i32, vp, C.POINTER(C.c_float)]
     lib.aslr_count_active.restype = C.c_int
     lib.aslr_count_active.argtypes = [vp, vp, C.POINTER(i32)]
     lib.aslr_dam_eval.restype = C.c_int

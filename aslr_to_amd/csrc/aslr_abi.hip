@@ -1,0 +1,475 @@
+// aslr_abi.hip -- the C ABI of include/aslr_to_amd.h: handle, workspace carving, solver driver.
+// The kernels live in aslr_calc_*.hip / aslr_backward_*.hip / aslr_forward_*.hip.
+#include <new>
+#include <vector>
+
+#include "aslr_common.hpp"
+
+using namespace aslr;
+
+namespace {
+thread_local char g_err_storage[kErrLen] = {0};
+}
+namespace aslr {
+char *err_buf() { return g_err_storage; }
+} // namespace aslr
+#define g_err g_err_storage
+
+namespace {
+
+// per-trajectory solver state at solve() entry
+__global__ void init_state_kernel(KArgs a, double reg0, int is_feasible) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int B = a.B;
+  for (int r = 0; r < ASLR_TF_COUNT; ++r) a.traj_f[r * B + b] = 0.0;
+  for (int r = 0; r < ASLR_TI_COUNT; ++r) a.traj_i[r * B + b] = 0;
+  a.traj_f[ASLR_TF_XREG * B + b] = reg0;
+  a.traj_i[ASLR_TI_FEASIBLE * B + b] = is_feasible;
+  a.traj_i[ASLR_TI_RECALC * B + b] = 1;
+  a.traj_i[ASLR_TI_ACCEPTED * B + b] = -1;
+}
+
+__global__ void reset_accepted_kernel(KArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < a.B) a.traj_i[ASLR_TI_ACCEPTED * a.B + b] = -1;
+}
+
+} // namespace
+
+// =================================================================================================
+// host side: handle, workspace carving, dispatch
+// =================================================================================================
+struct aslr_problem {
+  aslr_problem_desc_t desc; // host copy (pointers nulled)
+  int nj, nx, nu, dam, rec;
+  char *ws;
+  int64_t ws_bytes;
+  aslr_region_t regions[ASLR_R_COUNT];
+  KArgs k;
+  int32_t *h_done; // pinned staging for count_active
+  hipEvent_t ev[4];
+  bool have_ev;
+};
+
+namespace {
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+int desc_dims(const aslr_problem_desc_t *d, int *nj, int *nx, int *nu, int *dam) {
+  if (!d || d->B <= 0 || d->T <= 0 || d->nmodels <= 0 || d->nmodels > ASLR_MAX_MODELS) return ASLR_E_INVALID;
+  if (d->chain.nj <= 0 || d->chain.nj > ASLR_MAX_NJ) return ASLR_E_INVALID;
+  *nj = d->chain.nj;
+  *nx = 4 * d->chain.nj;
+  *nu = d->models[0].nu;
+  *dam = d->models[0].dam;
+  for (int i = 0; i < d->nmodels; ++i) {
+    const aslr_model_t &m = d->models[i];
+    if (m.nu != *nu || m.dam != *dam) return ASLR_E_INVALID; // one (nu, dam) per problem
+    if (m.dam == ASLR_DAM_VSA ? m.nu != 2 * *nj : m.nu != *nj) return ASLR_E_INVALID;
+    if (m.ncosts < 0 || m.ncosts > ASLR_MAX_COSTS) return ASLR_E_INVALID;
+    for (int c = 0; c < m.ncosts; ++c) {
+      const aslr_cost_t &ct = m.costs[c];
+      if (ct.type < 0 || ct.type > ASLR_COST_STIFFNESS) return ASLR_E_INVALID;
+      if (ct.type == ASLR_COST_FRAME_PLACEMENT && (ct.frame_joint < 0 || ct.frame_joint >= *nj)) return ASLR_E_INVALID;
+      if (ct.type == ASLR_COST_STIFFNESS && m.dam != ASLR_DAM_VSA) return ASLR_E_INVALID;
+      if (ct.type == ASLR_COST_PENDULUM && *nj < 2) return ASLR_E_INVALID;
+    }
+  }
+  return ASLR_OK;
+}
+
+void carve(const aslr_problem_desc_t *d, int nx, int nu, aslr_region_t *r, int64_t *total) {
+  const int64_t B = d->B, T = d->T, T1 = T + 1, rec = rec_len_c(nx, nu), D = sizeof(double);
+  int64_t sizes[ASLR_R_COUNT];
+  sizes[ASLR_R_XS] = T1 * B * nx * D;
+  sizes[ASLR_R_US] = T * B * nu * D;
+  sizes[ASLR_R_XNEXT] = T1 * B * nx * D;
+  sizes[ASLR_R_COST] = T1 * B * D;
+  sizes[ASLR_R_DERIV] = T1 * B * rec * D;
+  sizes[ASLR_R_GAPS] = T1 * B * nx * D;
+  sizes[ASLR_R_KGAIN] = T * B * nu * nx * D;
+  sizes[ASLR_R_KFF] = T * B * nu * D;
+  sizes[ASLR_R_QU] = T * B * nu * D;
+  sizes[ASLR_R_VX] = T1 * B * nx * D;
+  sizes[ASLR_R_VXX] = T1 * B * nx * nx * D;
+  sizes[ASLR_R_XS_TRY] = (int64_t)ASLR_NALPHA * T1 * B * nx * D;
+  sizes[ASLR_R_US_TRY] = (int64_t)ASLR_NALPHA * T * B * nu * D;
+  sizes[ASLR_R_TRAJ_F] = (int64_t)ASLR_TF_COUNT * B * D;
+  sizes[ASLR_R_TRAJ_I] = (int64_t)ASLR_TI_COUNT * B * sizeof(int32_t);
+  sizes[ASLR_R_X0] = B * nx * D;
+  sizes[ASLR_R_FRAME_REF] = B * 12 * D;
+  sizes[ASLR_R_VXXF] = T1 * B * nx * D;
+  sizes[ASLR_R_DESC] = sizeof(DevDesc);
+  sizes[ASLR_R_NODE_MODEL] = T1 * sizeof(int32_t);
+  int64_t off = 0;
+  for (int i = 0; i < ASLR_R_COUNT; ++i) {
+    r[i].offset = off;
+    r[i].bytes = sizes[i];
+    off += align_up(sizes[i], 256);
+  }
+  *total = off;
+}
+
+// Gauss-Jordan inverse of the motor inertia B (np.linalg.inv(self.B), free_fwddyn_asr.py:41)
+bool invert(int n, const double *A, double *Ainv) {
+  std::vector<double> a(n * 2 * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) { a[i * 2 * n + j] = A[i * n + j]; a[i * 2 * n + n + j] = i == j ? 1.0 : 0.0; }
+  for (int col = 0; col < n; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < n; ++r) if (std::fabs(a[r * 2 * n + col]) > std::fabs(a[piv * 2 * n + col])) piv = r;
+    if (a[piv * 2 * n + col] == 0.0) return false;
+    if (piv != col) for (int j = 0; j < 2 * n; ++j) std::swap(a[col * 2 * n + j], a[piv * 2 * n + j]);
+    const double d = a[col * 2 * n + col];
+    for (int j = 0; j < 2 * n; ++j) a[col * 2 * n + j] /= d;
+    for (int r = 0; r < n; ++r) if (r != col) {
+      const double f = a[r * 2 * n + col];
+      if (f != 0.0) for (int j = 0; j < 2 * n; ++j) a[r * 2 * n + j] -= f * a[col * 2 * n + j];
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) Ainv[i * n + j] = a[i * 2 * n + n + j];
+  return true;
+}
+
+// Planar restatement of the chain when every joint axis is +z and every joint placement is a rotation
+// about z (exact tests: the tables are built from exact 0 / 1 entries).  ASLR_NO_PLANAR=1 disables it.
+void fill_planar(const aslr_chain_t &c, PlanarChain *pl) {
+  memset(pl, 0, sizeof *pl);
+  const char *e = getenv("ASLR_NO_PLANAR");
+  if (e && atoi(e)) return;
+  double z = 0.0;
+  for (int i = 0; i < c.nj; ++i) {
+    const double *R = c.joint_R[i], *ax = c.axis[i];
+    if (!(ax[0] == 0.0 && ax[1] == 0.0 && ax[2] == 1.0)) return;
+    if (!(R[2] == 0.0 && R[5] == 0.0 && R[6] == 0.0 && R[7] == 0.0 && R[8] == 1.0)) return;
+    if (!(R[0] == R[4] && R[1] == -R[3])) return;
+    pl->cphi[i] = R[0];
+    pl->sphi[i] = R[3];
+    pl->px[i] = c.joint_p[i][0];
+    pl->py[i] = c.joint_p[i][1];
+    z += c.joint_p[i][2];
+    pl->pz[i] = z; // world height of joint frame i
+    pl->m[i] = c.mass[i];
+    pl->cx[i] = c.com[i][0];
+    pl->cy[i] = c.com[i][1];
+    pl->izz[i] = c.inertia[i][8];
+  }
+  pl->gx = c.gravity[0];
+  pl->gy = c.gravity[1];
+  pl->ok = 1;
+}
+
+SolverDev to_dev(const aslr_solver_params_t *sp, int standalone, int store_v) {
+  SolverDev s;
+  s.solver = sp->solver; s.fixed_iterations = sp->fixed_iterations;
+  s.th_stop = sp->th_stop; s.th_grad = sp->th_grad; s.th_gaptol = sp->th_gaptol;
+  s.th_stepdec = sp->th_stepdec; s.th_stepinc = sp->th_stepinc; s.th_acceptstep = sp->th_acceptstep;
+  s.th_acceptnegstep = sp->th_acceptnegstep;
+  s.reg_min = sp->reg_min; s.reg_max = sp->reg_max; s.reg_incfactor = sp->reg_incfactor;
+  s.reg_decfactor = sp->reg_decfactor;
+  s.boxqp_maxiter = sp->boxqp_maxiter; s.boxqp_th_acceptstep = sp->boxqp_th_acceptstep;
+  s.boxqp_th_grad = sp->boxqp_th_grad; s.boxqp_reg = sp->boxqp_reg;
+  s.standalone = standalone; s.store_v = store_v;
+  { const char *e = getenv("ASLR_DEBUG"); s.debug = e ? atoi(e) : 0; }
+  return s;
+}
+
+// ---- launch helpers: dispatch to the per-size translation units ----
+int launch_calc(aslr_problem *p, bool diff, int mode, double th_gaptol, hipStream_t st) {
+  if (p->nj == 2) return launch_calc_nj2(p->k, p->dam, diff, mode, th_gaptol, st);
+  if (p->nj == 7) return launch_calc_nj7(p->k, p->dam, diff, mode, th_gaptol, st);
+  snprintf(g_err, sizeof g_err, "unsupported nj=%d", p->nj);
+  return ASLR_E_INVALID;
+}
+
+int backward_hs(const aslr_problem *p) {
+  // rows of each column split over HS lanes: wider teams when the batch cannot fill the chip
+  const char *e = getenv("ASLR_BWD_HS");
+  if (e) return atoi(e);
+  return p->desc.B <= 8192 ? 2 : 1;
+}
+
+int launch_backward(aslr_problem *p, const SolverDev &sd, hipStream_t st) {
+  const int hs = backward_hs(p);
+  ModelLimits lim;
+  memset(&lim, 0, sizeof lim);
+  for (int i = 0; i < p->desc.nmodels; ++i) {
+    lim.has[i] = p->desc.models[i].has_u_limits;
+    for (int c = 0; c < ASLR_MAX_NU; ++c) { lim.lb[i][c] = p->desc.models[i].u_lb[c]; lim.ub[i][c] = p->desc.models[i].u_ub[c]; }
+  }
+  if (p->nx == 8) return launch_backward_nx8(p->k, p->nu, hs, sd, lim, st);
+  if (p->nx == 28) return launch_backward_nx28(p->k, p->nu, hs, sd, lim, st);
+  snprintf(g_err, sizeof g_err, "unsupported (nx=%d, nu=%d)", p->nx, p->nu);
+  return ASLR_E_INVALID;
+}
+
+int launch_forward(aslr_problem *p, const SolverDev &sd, hipStream_t st) {
+  if (p->nj == 2) return launch_forward_nj2(p->k, p->dam, sd, st);
+  if (p->nj == 7) return launch_forward_nj7(p->k, p->dam, sd, st);
+  snprintf(g_err, sizeof g_err, "unsupported nj=%d", p->nj);
+  return ASLR_E_INVALID;
+}
+
+} // namespace
+
+extern "C" {
+
+int aslr_abi_version(void) { return ASLR_ABI_VERSION; }
+
+int64_t aslr_sizeof(int which) {
+  switch (which) {
+  case 0: return sizeof(aslr_chain_t);
+  case 1: return sizeof(aslr_cost_t);
+  case 2: return sizeof(aslr_model_t);
+  case 3: return sizeof(aslr_problem_desc_t);
+  case 4: return sizeof(aslr_solver_params_t);
+  case 5: return sizeof(aslr_region_t);
+  default: return -1;
+  }
+}
+
+int32_t aslr_record_len(int32_t nx, int32_t nu) { return rec_len_c(nx, nu); }
+
+void aslr_solver_params_default(aslr_solver_params_t *p, int32_t solver) {
+  memset(p, 0, sizeof *p);
+  p->solver = solver;
+  p->maxiter = 100;
+  p->reg_init = NAN;
+  p->th_stop = 1e-9;
+  p->th_grad = 1e-12;
+  p->th_gaptol = 1e-16;
+  p->th_stepdec = 0.5;
+  p->th_stepinc = 0.01;
+  p->th_acceptstep = 0.1;
+  p->th_acceptnegstep = 2.0;
+  p->reg_min = 1e-9;
+  p->reg_max = 1e9;
+  p->reg_incfactor = 10.0;
+  p->reg_decfactor = 10.0;
+  p->boxqp_maxiter = 100;
+  p->boxqp_th_acceptstep = 0.1;
+  p->boxqp_th_grad = 1e-5;
+  p->boxqp_reg = 0.0;
+}
+
+int64_t aslr_workspace_bytes(const aslr_problem_desc_t *desc) {
+  int nj, nx, nu, dam;
+  if (desc_dims(desc, &nj, &nx, &nu, &dam)) return ASLR_E_INVALID;
+  aslr_region_t r[ASLR_R_COUNT];
+  int64_t total;
+  carve(desc, nx, nu, r, &total);
+  return total;
+}
+
+int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_t workspace_bytes, void *stream,
+                        aslr_problem_t **out) {
+  if (!out) return ASLR_E_INVALID;
+  *out = nullptr;
+  int nj, nx, nu, dam;
+  if (desc_dims(desc, &nj, &nx, &nu, &dam)) { snprintf(g_err, sizeof g_err, "invalid problem description"); return ASLR_E_INVALID; }
+  if (!desc->node_model || !desc->x0) return ASLR_E_INVALID;
+  for (int t = 0; t <= desc->T; ++t)
+    if (desc->node_model[t] < 0 || desc->node_model[t] >= desc->nmodels) return ASLR_E_INVALID;
+  if (!((nj == 2) || (nj == 7 && dam == ASLR_DAM_SEA))) {
+    snprintf(g_err, sizeof g_err, "unsupported (nj=%d, dam=%d): built for nj=2 SEA/VSA, nj=7 SEA", nj, dam);
+    return ASLR_E_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { snprintf(g_err, sizeof g_err, "no HIP device"); return ASLR_E_NODEVICE; }
+  aslr_problem *p = new (std::nothrow) aslr_problem();
+  if (!p) return ASLR_E_INVALID;
+  p->desc = *desc;
+  p->desc.node_model = nullptr; p->desc.x0 = nullptr; p->desc.frame_ref = nullptr;
+  p->nj = nj; p->nx = nx; p->nu = nu; p->dam = dam; p->rec = rec_len_c(nx, nu);
+  int64_t total;
+  carve(desc, nx, nu, p->regions, &total);
+  if (!workspace || workspace_bytes < total || (reinterpret_cast<uintptr_t>(workspace) & 255u)) {
+    snprintf(g_err, sizeof g_err, "workspace needs %lld bytes, 256-B aligned (got %lld)", (long long)total, (long long)workspace_bytes);
+    delete p;
+    return ASLR_E_WORKSPACE;
+  }
+  p->ws = static_cast<char *>(workspace);
+  p->ws_bytes = workspace_bytes;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto reg = [&](int id) { return p->ws + p->regions[id].offset; };
+  // device description (with Binv)
+  DevDesc *hd = new DevDesc();
+  memset(hd, 0, sizeof *hd);
+  hd->chain = desc->chain;
+  fill_planar(desc->chain, &hd->planar);
+  const int planar_ok = hd->planar.ok;
+  for (int i = 0; i < desc->nmodels; ++i) {
+    hd->models[i].m = desc->models[i];
+    if (!invert(nj, desc->models[i].B, hd->models[i].Binv)) {
+      snprintf(g_err, sizeof g_err, "motor inertia B of model %d is singular", i);
+      delete hd; delete p;
+      return ASLR_E_INVALID;
+    }
+  }
+  hipError_t e = hipMemcpyAsync(reg(ASLR_R_DESC), hd, sizeof(DevDesc), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(reg(ASLR_R_NODE_MODEL), desc->node_model, sizeof(int32_t) * (desc->T + 1), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(reg(ASLR_R_X0), desc->x0, sizeof(double) * desc->B * nx, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && desc->frame_ref) e = hipMemcpyAsync(reg(ASLR_R_FRAME_REF), desc->frame_ref, sizeof(double) * desc->B * 12, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemsetAsync(reg(ASLR_R_TRAJ_I), 0, p->regions[ASLR_R_TRAJ_I].bytes, st);
+  if (e == hipSuccess) e = hipMemsetAsync(reg(ASLR_R_TRAJ_F), 0, p->regions[ASLR_R_TRAJ_F].bytes, st);
+  if (e == hipSuccess) e = hipMemsetAsync(reg(ASLR_R_GAPS), 0, p->regions[ASLR_R_GAPS].bytes, st);
+  if (e == hipSuccess) e = hipMemsetAsync(reg(ASLR_R_KFF), 0, p->regions[ASLR_R_KFF].bytes, st);
+  if (e == hipSuccess) e = hipMemsetAsync(reg(ASLR_R_VXXF), 0, p->regions[ASLR_R_VXXF].bytes, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st); // the host staging buffers die below
+  delete hd;
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_done), sizeof(int32_t) * desc->B, 0);
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof g_err, "upload failed: %s", hipGetErrorString(e));
+    delete p;
+    return ASLR_E_HIP;
+  }
+  KArgs &k = p->k;
+  k.desc = reinterpret_cast<const DevDesc *>(reg(ASLR_R_DESC));
+  k.node_model = reinterpret_cast<const int32_t *>(reg(ASLR_R_NODE_MODEL));
+  k.x0 = reinterpret_cast<const double *>(reg(ASLR_R_X0));
+  k.frame_ref = desc->frame_ref ? reinterpret_cast<const double *>(reg(ASLR_R_FRAME_REF)) : nullptr;
+  k.xs = (double *)reg(ASLR_R_XS); k.us = (double *)reg(ASLR_R_US); k.xnext = (double *)reg(ASLR_R_XNEXT);
+  k.cost = (double *)reg(ASLR_R_COST); k.deriv = (double *)reg(ASLR_R_DERIV); k.gaps = (double *)reg(ASLR_R_GAPS);
+  k.kgain = (double *)reg(ASLR_R_KGAIN); k.kff = (double *)reg(ASLR_R_KFF); k.qu = (double *)reg(ASLR_R_QU);
+  k.vx = (double *)reg(ASLR_R_VX); k.vxx = (double *)reg(ASLR_R_VXX); k.xs_try = (double *)reg(ASLR_R_XS_TRY);
+  k.us_try = (double *)reg(ASLR_R_US_TRY); k.vxxf = (double *)reg(ASLR_R_VXXF);
+  k.traj_f = (double *)reg(ASLR_R_TRAJ_F); k.traj_i = (int32_t *)reg(ASLR_R_TRAJ_I);
+  k.B = desc->B; k.T = desc->T;
+  k.planar = planar_ok;
+  *out = p;
+  return ASLR_OK;
+}
+
+int aslr_problem_destroy(aslr_problem_t *p) {
+  if (!p) return ASLR_OK;
+  if (p->h_done) (void)hipHostFree(p->h_done);
+  if (p->have_ev) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(p->ev[i]);
+  delete p;
+  return ASLR_OK;
+}
+
+int aslr_problem_region(const aslr_problem_t *p, int32_t region_id, aslr_region_t *out) {
+  if (!p || !out || region_id < 0 || region_id >= ASLR_R_COUNT) return ASLR_E_INVALID;
+  *out = p->regions[region_id];
+  return ASLR_OK;
+}
+
+int aslr_calc(aslr_problem_t *p, void *stream) {
+  if (!p) return ASLR_E_INVALID;
+  return launch_calc(p, false, 0, -1.0, static_cast<hipStream_t>(stream));
+}
+
+int aslr_calc_diff(aslr_problem_t *p, void *stream) {
+  if (!p) return ASLR_E_INVALID;
+  return launch_calc(p, true, 0, -1.0, static_cast<hipStream_t>(stream));
+}
+
+int aslr_backward_pass(aslr_problem_t *p, const aslr_solver_params_t *sp, void *stream) {
+  if (!p || !sp) return ASLR_E_INVALID;
+  return launch_backward(p, to_dev(sp, 1, 1), static_cast<hipStream_t>(stream));
+}
+
+int aslr_forward_pass(aslr_problem_t *p, const aslr_solver_params_t *sp, void *stream) {
+  if (!p || !sp) return ASLR_E_INVALID;
+  return launch_forward(p, to_dev(sp, 1, 0), static_cast<hipStream_t>(stream));
+}
+
+int aslr_iterate(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream) {
+  if (!p || !sp) return ASLR_E_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (first) {
+    const double reg0 = std::isnan(sp->reg_init) ? sp->reg_min : sp->reg_init;
+    hipLaunchKernelGGL(init_state_kernel, dim3((p->desc.B + 255) / 256), dim3(256), 0, st, p->k, reg0, sp->is_feasible);
+    HIP_TRY(hipGetLastError());
+  }
+  const SolverDev sd = to_dev(sp, 0, 0);
+  int rc = launch_calc(p, true, kModeCommit | kModeSolver, sp->th_gaptol, st);
+  if (rc) return rc;
+  rc = launch_backward(p, sd, st);
+  if (rc) return rc;
+  return launch_forward(p, sd, st);
+}
+
+int aslr_iterate_timed(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream, float *ms3) {
+  if (!p || !sp || !ms3) return ASLR_E_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!p->have_ev) {
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&p->ev[i]));
+    p->have_ev = true;
+  }
+  if (first) {
+    const double reg0 = std::isnan(sp->reg_init) ? sp->reg_min : sp->reg_init;
+    hipLaunchKernelGGL(init_state_kernel, dim3((p->desc.B + 255) / 256), dim3(256), 0, st, p->k, reg0, sp->is_feasible);
+    HIP_TRY(hipGetLastError());
+  }
+  const SolverDev sd = to_dev(sp, 0, 0);
+  HIP_TRY(hipEventRecord(p->ev[0], st));
+  int rc = launch_calc(p, true, kModeCommit | kModeSolver, sp->th_gaptol, st);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(p->ev[1], st));
+  rc = launch_backward(p, sd, st);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(p->ev[2], st));
+  rc = launch_forward(p, sd, st);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(p->ev[3], st));
+  HIP_TRY(hipEventSynchronize(p->ev[3]));
+  for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&ms3[i], p->ev[i], p->ev[i + 1]));
+  return ASLR_OK;
+}
+
+int aslr_finalize(aslr_problem_t *p, void *stream) {
+  if (!p) return ASLR_E_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = launch_calc(p, false, kModeCommit | kModeNoCompute, -1.0, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(reset_accepted_kernel, dim3((p->desc.B + 255) / 256), dim3(256), 0, st, p->k);
+  HIP_TRY(hipGetLastError());
+  return ASLR_OK;
+}
+
+int aslr_count_active(aslr_problem_t *p, void *stream, int32_t *active) {
+  if (!p || !active) return ASLR_E_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int B = p->desc.B;
+  HIP_TRY(hipMemcpyAsync(p->h_done, p->k.traj_i + (size_t)ASLR_TI_DONE * B, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  int n = 0;
+  for (int b = 0; b < B; ++b) n += p->h_done[b] ? 0 : 1;
+  *active = n;
+  return ASLR_OK;
+}
+
+int aslr_solve(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t poll_every, void *stream, int32_t *iters_done) {
+  if (!p || !sp) return ASLR_E_INVALID;
+  int it = 0;
+  for (; it < sp->maxiter; ++it) {
+    int rc = aslr_iterate(p, sp, it == 0, stream);
+    if (rc) return rc;
+    if (!sp->fixed_iterations && poll_every > 0 && (it + 1) % poll_every == 0 && it + 1 < sp->maxiter) {
+      int32_t active = 0;
+      rc = aslr_count_active(p, stream, &active);
+      if (rc) return rc;
+      if (active == 0) { ++it; break; }
+    }
+  }
+  if (iters_done) *iters_done = it;
+  return aslr_finalize(p, stream);
+}
+
+int aslr_dam_eval(aslr_problem_t *p, int32_t model_index, int32_t n, const double *x, const double *u, double *xout,
+                  double *cost, double *Fx, double *Fu, double *Lx, double *Lu, double *Lxx, double *Lxu, double *Luu,
+                  void *stream) {
+  if (!p || n <= 0 || model_index < 0 || model_index >= p->desc.nmodels || !x || !u) return ASLR_E_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p->nj == 2) return launch_dam_eval_nj2(p->k, p->dam, model_index, n, x, u, xout, cost, Fx, Fu, Lx, Lu, Lxx, Lxu, Luu, st);
+  if (p->nj == 7) return launch_dam_eval_nj7(p->k, p->dam, model_index, n, x, u, xout, cost, Fx, Fu, Lx, Lu, Lxx, Lxu, Luu, st);
+  snprintf(g_err, sizeof g_err, "unsupported nj=%d", p->nj);
+  return ASLR_E_INVALID;
+}
+
+const char *aslr_last_error(void) { return g_err; }
+
+} // extern "C"

@@ -1,0 +1,504 @@
+// aslr_backward.inc.hpp -- Riccati backward pass kernel (SolverDDP.backwardPass + computeGains,
+// SolverBoxDDP.computeGains + BoxQP)
+//
+// One TEAM of lanes per trajectory; lane (h, j) owns rows [h*RPL, (h+1)*RPL) of column j of every
+// nx-column matrix.  Vxx / Vx of the next knot live in registers (each lane holds the whole column j
+// of the symmetric Vxx, which is also its row j); products stream one operand from LDS as a
+// broadcast row and keep the other in registers.  The per-knot DERIV record, the box-QP inputs and
+// the gap vector of knot t-1 are prefetched into registers while knot t computes.
+//
+// The kernel is bound by the instruction stream of ONE wave per SIMD (B = 4096 gives 1024 waves of
+// 4 teams), so the code avoids selects / clamps / divisions in the loop: rows divide evenly for
+// nx = 8, pivots use rsqrt, the NaN test is one sum per lane.
+#pragma once
+#include "aslr_common.hpp"
+
+namespace aslr {
+
+// Cholesky with reciprocal pivots from rsqrt: L (lower, in place), rinv[i] = 1 / L[i][i].
+// Returns true on a non-positive (or NaN) pivot, like Eigen::LLT info() != Success.
+template <int N>
+ASLR_DEV bool chol_rs(double (&A)[N][N], double (&rinv)[N]) {
+  bool bad = false;
+  ASLR_UNROLL for (int j = 0; j < N; ++j) {
+    double d = A[j][j];
+    ASLR_UNROLL for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+    if (!(d > 0.0)) bad = true;
+    const double ri = rsqrt(d);
+    rinv[j] = ri;
+    A[j][j] = d * ri;
+    ASLR_UNROLL for (int i = j + 1; i < N; ++i) {
+      double s = A[i][j];
+      ASLR_UNROLL for (int k = 0; k < j; ++k) s -= A[i][k] * A[j][k];
+      A[i][j] = s * ri;
+    }
+  }
+  return bad;
+}
+
+// BoxQP on register arrays, evaluated redundantly by every lane of a team.  The free
+// subspace is handled by masking: clamped rows/columns of H become identity rows, which makes the
+// Cholesky of the masked matrix reproduce the factor of Hff exactly (the extra operands are 0 / 1).
+// On exit: x, the clamped mask of the final active set, and in `kcol` the column Quu_inv * kcol_in
+// where Quu_inv is zero outside the free block and Hff^-1 inside (Crocoddyl forms Hff^-1 explicitly
+// and multiplies; solving with the same factor differs by rounding only).  The factor of the last
+// Newton step is reused when the final active set is the one it was built for.
+template <int NU>
+ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const double (&lb)[NU],
+                    const double (&ub)[NU], double (&x)[NU], bool (&cm)[NU], double (&kcol)[NU],
+                    int boxqp_maxiter, double th_acceptstep, double th_grad, double reg) {
+  bool bad = false, finished = false, have_factor = false;
+  bool cmL[NU];
+  double L[NU][NU], rinv[NU];
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) { x[i] = fmax(fmin(x[i], ub[i]), lb[i]); cm[i] = false; cmL[i] = false; }
+  int nf = NU;
+  for (int it = 0; it < boxqp_maxiter; ++it) {
+    if (!finished) {
+      double g[NU];
+      ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+        double s = q[i];
+        ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
+        g[i] = s;
+      }
+      double gnorm = 0.0;
+      nf = 0;
+      ASLR_UNROLL for (int j = 0; j < NU; ++j) {
+        cm[j] = (x[j] == lb[j] && g[j] > 0.0) || (x[j] == ub[j] && g[j] < 0.0);
+        if (!cm[j]) { gnorm = fmax(gnorm, fabs(g[j])); ++nf; }
+      }
+      if (gnorm <= th_grad || nf == 0) {
+        finished = true;
+      } else {
+        ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+          cmL[i] = cm[i];
+          ASLR_UNROLL for (int j = 0; j < NU; ++j)
+            L[i][j] = (cm[i] || cm[j]) ? (i == j ? 1.0 : 0.0) : (H[i][j] + (i == j ? reg : 0.0));
+        }
+        have_factor = true;
+        if (chol_rs<NU>(L, rinv)) { bad = true; finished = true; }
+        // dx_f = -Hff^-1 (q_f + H_fc x_c) - x_f
+        double rhs[NU], dx[NU];
+        ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+          double s = -q[i];
+          ASLR_UNROLL for (int j = 0; j < NU; ++j) if (cm[j]) s -= H[i][j] * x[j];
+          rhs[i] = cm[i] ? 0.0 : s;
+        }
+        chol_solve_r<NU>(L, rinv, rhs);
+        double fold = 0.0;
+        ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+          dx[i] = cm[i] ? 0.0 : rhs[i] - x[i];
+          double s = 0.0;
+          ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
+          fold += 0.5 * x[i] * s + q[i] * x[i];
+        }
+        double alpha = 1.0;
+        bool found = false;
+        for (int al = 0; al < ASLR_NALPHA; ++al, alpha *= 0.5) {
+          if (!found) {
+            double xn[NU], fnew = 0.0, gd = 0.0;
+            ASLR_UNROLL for (int i = 0; i < NU; ++i) xn[i] = fmax(fmin(x[i] + alpha * dx[i], ub[i]), lb[i]);
+            ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+              double s = 0.0;
+              ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * xn[j];
+              fnew += 0.5 * xn[i] * s + q[i] * xn[i];
+              gd += g[i] * (x[i] - xn[i]);
+            }
+            if (fold - fnew > th_acceptstep * gd) {
+              ASLR_UNROLL for (int i = 0; i < NU; ++i) x[i] = xn[i];
+              found = true;
+            }
+          }
+          if (__ballot(!found) == 0ull) break;
+        }
+      }
+    }
+    if (__ballot(!finished) == 0ull) break;
+  }
+  // factor of the final free block (kept from the last Newton step when the active set is unchanged)
+  bool same = have_factor;
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) same = same && (cmL[i] == cm[i]);
+  if (!same) {
+    ASLR_UNROLL for (int i = 0; i < NU; ++i)
+      ASLR_UNROLL for (int j = 0; j < NU; ++j)
+        L[i][j] = (cm[i] || cm[j]) ? (i == j ? 1.0 : 0.0) : (H[i][j] + (i == j ? reg : 0.0));
+    if (chol_rs<NU>(L, rinv) && nf > 0) bad = true;
+  }
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) if (cm[i]) kcol[i] = 0.0;
+  chol_solve_r<NU>(L, rinv, kcol);
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) if (cm[i]) kcol[i] = 0.0;
+  return bad;
+}
+
+template <int NX, int NU, int HS>
+struct BwdCfg {
+  static constexpr int NXP = NX <= 8 ? 8 : 32;
+  static constexpr int TEAM = NXP * HS;
+  static constexpr int TPW = 64 / TEAM;
+  static constexpr int RPL = (NX + HS - 1) / HS;
+  static constexpr bool EXACT = (RPL * HS == NX); // rows divide evenly: no clamping of row indices
+  static constexpr int REC = rec_len_c(NX, NU);
+  static constexpr int oFx = 0, oFu = oFx + NX * NX, oLxx = oFu + NX * NU, oLxu = oLxx + NX * NX,
+                       oLuu = oLxu + NX * NU, oLx = oLuu + NU * NU, oLu = oLx + NX;
+  // LDS arrays per team (doubles)
+  static constexpr int sRec = 0, sAT = sRec + REC, sBT = sAT + NX * NX, sQux = sBT + NX * NU,
+                       sVT = sQux + NU * NX, sQuu = sVT + NX * NX, sQu = sQuu + NU * NU, sVx = sQu + NU,
+                       sEnd = sVx + NX;
+  static constexpr int LDS_TEAM = (sEnd + 1) / 2 * 2;
+  static constexpr int NPRE = (REC / 2 + TEAM - 1) / TEAM; // double2 prefetch registers per lane
+};
+
+template <int NX, int NU, int HS>
+__global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
+  using C = BwdCfg<NX, NU, HS>;
+  constexpr int NXP = C::NXP, TEAM = C::TEAM, TPW = C::TPW, RPL = C::RPL, REC = C::REC;
+  extern __shared__ double smem[];
+
+  const int lane = threadIdx.x, team = lane / TEAM, lt = lane % TEAM, j = lt % NXP, h = lt / NXP;
+  const int B = a.B, T = a.T;
+  const int bq = blockIdx.x * TPW + team;
+  const bool team_valid = bq < B;
+  const int b = team_valid ? bq : B - 1;
+  const bool col_valid = j < NX;
+  const int jj = col_valid ? j : NX - 1;
+  const bool writer = team_valid && col_valid && h == 0;
+  const int r0 = h * RPL;
+  const int ju = jj < NU ? jj : NU - 1;
+  double *sm = smem + team * C::LDS_TEAM;
+  double *rec = sm + C::sRec, *AT = sm + C::sAT, *BT = sm + C::sBT, *QuxL = sm + C::sQux, *VT = sm + C::sVT,
+         *QuuL = sm + C::sQuu, *QuL = sm + C::sQu, *VxL = sm + C::sVx;
+  auto row = [&](int i) { return C::EXACT ? r0 + i : (r0 + i < NX ? r0 + i : NX - 1); };
+  auto row_ok = [&](int i) { return C::EXACT ? true : (r0 + i < NX); };
+
+  int32_t *TI = a.traj_i;
+  double *TF = a.traj_f;
+
+  // ---- prologue: solver-state bookkeeping that Crocoddyl does inside calcDiff ----
+  int done = 0, feasible = TI[ASLR_TI_FEASIBLE * B + b], status = TI[ASLR_TI_STATUS * B + b];
+  if (!sp.standalone) {
+    done = TI[ASLR_TI_DONE * B + b];
+    const int recalc = TI[ASLR_TI_RECALC * B + b];
+    if (!done && recalc) {
+      if (!feasible) feasible = TI[ASLR_TI_GAPFLAG * B + b] ? 0 : 1;
+      // cost_ = sum of node costs, in node order
+      double csum = 0.0;
+      for (int t = 0; t <= T; ++t) csum += a.cost[(size_t)t * B + b];
+      if (lt == 0 && team_valid) TF[ASLR_TF_COST * B + b] = csum;
+    }
+    wave_sync();
+    if (lt == 0 && team_valid) {
+      TI[ASLR_TI_FEASIBLE * B + b] = feasible;
+      TI[ASLR_TI_ACCEPTED * B + b] = -1;
+      TI[ASLR_TI_GAPFLAG * B + b] = 0;
+    }
+  }
+  bool need = team_valid && !done;
+  if (__ballot(need) == 0ull) return;
+  double xreg = TF[ASLR_TF_XREG * B + b];
+  const bool fddp = sp.solver == ASLR_SOLVER_FDDP;
+  const bool box = sp.solver == ASLR_SOLVER_BOXDDP && feasible;
+  const bool gaps_on = !feasible;
+  const unsigned long long team_mask = (TEAM == 64 ? ~0ull : ((1ull << TEAM) - 1ull)) << (team * TEAM);
+
+  // one-hot selectors of this lane's diagonal / control row (FMA instead of compare + select in the loop)
+  double oh_row[RPL], oh_u[NU];
+  ASLR_UNROLL for (int i = 0; i < RPL; ++i) oh_row[i] = (r0 + i == jj) ? 1.0 : 0.0;
+  ASLR_UNROLL for (int c = 0; c < NU; ++c) oh_u[c] = (c == j) ? 1.0 : 0.0;
+
+  double d1 = 0.0, d2 = 0.0, stop = 0.0, dgf = 0.0, dqf = 0.0;
+  while (__ballot(need) != 0ull) {
+    bool failed = false;
+    d1 = d2 = stop = dgf = dqf = 0.0;
+    const double xr = isnan(xreg) ? 0.0 : xreg;
+    double Pcol[NX], pvec[NX], Vx_own;
+    // ---- terminal node: Vxx = Lxx (+xreg), Vx = Lx (+ Vxx f) ----
+    {
+      const double *rT = a.deriv + ((size_t)T * B + b) * REC;
+      ASLR_UNROLL for (int r = 0; r < NX; ++r) Pcol[r] = rT[C::oLxx + r * NX + jj] + (r == jj ? xr : 0.0);
+      Vx_own = rT[C::oLx + jj];
+      if (gaps_on) {
+        const double *f = a.gaps + ((size_t)T * B + b) * NX;
+        double vf = 0.0;
+        ASLR_UNROLL for (int r = 0; r < NX; ++r) vf += Pcol[r] * f[r];
+        Vx_own += vf;
+        if (fddp) {
+          dgf -= Vx_own * f[jj];
+          dqf += f[jj] * vf;
+          if (writer && need) a.vxxf[((size_t)T * B + b) * NX + jj] = vf;
+        }
+      }
+      if (sp.store_v && writer && need) {
+        a.vx[((size_t)T * B + b) * NX + jj] = Vx_own;
+        double *o = a.vxx + ((size_t)T * B + b) * NX * NX;
+        ASLR_UNROLL for (int r = 0; r < NX; ++r) o[r * NX + jj] = Pcol[r];
+      }
+      wave_sync();
+      VxL[jj] = Vx_own;
+      wave_sync();
+      ASLR_UNROLL for (int l = 0; l < NX; ++l) pvec[l] = VxL[l];
+    }
+    // ---- prefetch for knot T-1: record, model index, box-QP inputs, gap ----
+    double2 pre[C::NPRE];
+    double pre_u[NU], pre_k[NU], pre_f[NX];
+    int pre_m = 0;
+    ASLR_UNROLL for (int c = 0; c < NU; ++c) { pre_u[c] = 0.0; pre_k[c] = 0.0; }
+    ASLR_UNROLL for (int r = 0; r < NX; ++r) pre_f[r] = 0.0;
+    auto prefetch = [&](int t) {
+      const size_t tb = (size_t)t * B + b;
+      const double2 *src = reinterpret_cast<const double2 *>(a.deriv + tb * REC);
+      ASLR_UNROLL for (int i = 0; i < C::NPRE; ++i) {
+        const int idx = lt + TEAM * i;
+        if (C::NPRE * TEAM == REC / 2 || idx < REC / 2) pre[i] = src[idx];
+      }
+      pre_m = a.node_model[t];
+      if (box) {
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) { pre_u[c] = a.us[tb * NU + c]; pre_k[c] = a.kff[tb * NU + c]; }
+      }
+      if (gaps_on) {
+        ASLR_UNROLL for (int r = 0; r < NX; ++r) pre_f[r] = a.gaps[tb * NX + r];
+      }
+    };
+    prefetch(T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+      const size_t tb = (size_t)t * B + b;
+      // stage the record in LDS, take this knot's small inputs, start the next loads
+      {
+        double2 *dst = reinterpret_cast<double2 *>(rec);
+        ASLR_UNROLL for (int i = 0; i < C::NPRE; ++i) {
+          const int idx = lt + TEAM * i;
+          if (C::NPRE * TEAM == REC / 2 || idx < REC / 2) dst[idx] = pre[i];
+        }
+      }
+      double ut[NU], k0[NU], fg[NX];
+      ASLR_UNROLL for (int c = 0; c < NU; ++c) { ut[c] = pre_u[c]; k0[c] = pre_k[c]; }
+      ASLR_UNROLL for (int r = 0; r < NX; ++r) fg[r] = pre_f[r];
+      const int mi = pre_m;
+      wave_sync();
+      if (t > 0 && !(sp.debug & 2)) prefetch(t - 1);
+
+      // ---- step 1: A = Fx^T P (my rows of column jj), Bc = Fu^T P (column jj), Qx, Qu ----
+      double Fxcol[NX], Fucol[NX];
+      ASLR_UNROLL for (int l = 0; l < NX; ++l) { Fxcol[l] = rec[C::oFx + l * NX + jj]; Fucol[l] = rec[C::oFu + l * NU + ju]; }
+      {
+        double Arow[RPL], Bc[NU];
+        ASLR_UNROLL for (int i = 0; i < RPL; ++i) Arow[i] = 0.0;
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) Bc[c] = 0.0;
+        ASLR_UNROLL for (int l = 0; l < NX; ++l) {
+          ASLR_UNROLL for (int i = 0; i < RPL; ++i) Arow[i] += rec[C::oFx + l * NX + row(i)] * Pcol[l];
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) Bc[c] += rec[C::oFu + l * NU + c] * Pcol[l];
+        }
+        ASLR_UNROLL for (int i = 0; i < RPL; ++i) if (row_ok(i)) AT[jj * NX + r0 + i] = Arow[i];
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) BT[jj * NU + c] = Bc[c];
+      }
+      double Qx, Qu_own;
+      {
+        double s = 0.0, s2 = 0.0;
+        ASLR_UNROLL for (int l = 0; l < NX; ++l) { s += Fxcol[l] * pvec[l]; s2 += Fucol[l] * pvec[l]; }
+        Qx = rec[C::oLx + jj] + s;
+        Qu_own = rec[C::oLu + ju] + s2;
+      }
+      wave_sync();
+      // ---- step 2: Qxx (my rows), Qux (column jj), Quu (column jj < NU) ----
+      double Qxx[RPL], Qux[NU];
+      {
+        double acc[RPL], accu[NU], accq[NU];
+        ASLR_UNROLL for (int i = 0; i < RPL; ++i) acc[i] = 0.0;
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) { accu[c] = 0.0; accq[c] = 0.0; }
+        ASLR_UNROLL for (int l = 0; l < NX; ++l) {
+          ASLR_UNROLL for (int i = 0; i < RPL; ++i) acc[i] += AT[l * NX + row(i)] * Fxcol[l];
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+            const double bt = BT[l * NU + c];
+            accu[c] += bt * Fxcol[l];
+            accq[c] += bt * Fucol[l];
+          }
+        }
+        ASLR_UNROLL for (int i = 0; i < RPL; ++i) Qxx[i] = rec[C::oLxx + row(i) * NX + jj] + acc[i];
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+          Qux[c] = rec[C::oLxu + jj * NU + c] + accu[c];
+          QuxL[c * NX + jj] = Qux[c];
+        }
+        if (j < NU) {
+          ASLR_UNROLL for (int c = 0; c < NU; ++c)
+            QuuL[c * NU + j] = rec[C::oLuu + c * NU + j] + accq[c] + oh_u[c] * xr;
+          QuL[j] = Qu_own;
+        }
+      }
+      wave_sync();
+      // ---- step 3: gains (redundant per lane) ----
+      double Quu[NU][NU], qu[NU], kv[NU], Kc[NU];
+      ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+        qu[c] = QuL[c];
+        ASLR_UNROLL for (int e = 0; e < NU; ++e) Quu[c][e] = QuuL[c * NU + e];
+      }
+      // plain DDP gains: K = Quu^-1 Qux, k = Quu^-1 Qu
+      {
+        double L[NU][NU], rinv[NU];
+        ASLR_UNROLL for (int c = 0; c < NU; ++c)
+          ASLR_UNROLL for (int e = 0; e < NU; ++e) L[c][e] = Quu[c][e];
+        if (chol_rs<NU>(L, rinv)) failed = true;
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) { kv[c] = qu[c]; Kc[c] = Qux[c]; }
+        chol_solve_r<NU>(L, rinv, kv);
+        chol_solve_r<NU>(L, rinv, Kc);
+      }
+      if (box && lim.has[mi]) {
+        // SolverBoxDDP::computeGains.  BoxQP's first iteration is replayed exactly (clamped warm start
+        // x0, gradient, active set).  When no index is clamped there, the QP iteration has two cheap
+        // outcomes that need no projected-Newton loop:
+        //   (a) |g(x0)|_inf <= th_grad: BoxQP returns x0 itself with every index free;
+        //   (b) otherwise it takes the full Newton step to the unconstrained minimiser -Quu^-1 Qu; when
+        //       that point is strictly inside the box the step is accepted at alpha = 1 and the next
+        //       gradient test passes, again with every index free.
+        // In both, Hff^-1 = Quu^-1, so K is the plain gain above.  Everything else runs BoxQP.
+        double lb[NU], ub[NU], x0[NU], g0[NU];
+        bool any_clamped = false, interior = !failed && sp.boxqp_reg == 0.0;
+        double gnorm0 = 0.0;
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+          lb[c] = lim.lb[mi][c] - ut[c];
+          ub[c] = lim.ub[mi][c] - ut[c];
+          x0[c] = fmax(fmin(k0[c], ub[c]), lb[c]);
+        }
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+          double sg = qu[c];
+          ASLR_UNROLL for (int e = 0; e < NU; ++e) sg += Quu[c][e] * x0[e];
+          g0[c] = sg;
+          any_clamped = any_clamped || (x0[c] == lb[c] && sg > 0.0) || (x0[c] == ub[c] && sg < 0.0);
+          gnorm0 = fmax(gnorm0, fabs(sg));
+          const double dlt = -kv[c], mrg = 1e-9 * (1.0 + fabs(dlt));
+          interior = interior && (dlt > lb[c] + mrg) && (dlt < ub[c] - mrg);
+        }
+        if (!any_clamped && !failed && sp.boxqp_reg == 0.0 && gnorm0 <= sp.boxqp_th_grad) {
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) kv[c] = -x0[c]; // (a)
+        } else if (!any_clamped && interior) {
+          // (b): kv, Kc already hold the result
+        } else {
+          double xq[NU];
+          bool cm[NU];
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) { xq[c] = k0[c]; Kc[c] = Qux[c]; }
+          if (boxqp<NU>(Quu, qu, lb, ub, xq, cm, Kc, sp.boxqp_maxiter, sp.boxqp_th_acceptstep, sp.boxqp_th_grad,
+                        sp.boxqp_reg)) failed = true;
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+            kv[c] = -xq[c];
+            if (cm[c]) qu[c] = 0.0;
+          }
+        }
+      }
+      double Quuk[NU];
+      ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+        double s = 0.0;
+        ASLR_UNROLL for (int e = 0; e < NU; ++e) s += Quu[c][e] * kv[e];
+        Quuk[c] = s;
+      }
+      ASLR_UNROLL for (int c = 0; c < NU; ++c) { d1 += qu[c] * kv[c]; d2 -= kv[c] * Quuk[c]; stop += qu[c] * qu[c]; }
+      {
+        double s = 0.0, s2 = 0.0;
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) { s += Kc[c] * Quuk[c]; s2 += Kc[c] * qu[c]; }
+        Vx_own = Qx + s - 2.0 * s2;
+      }
+      {
+        double acc[RPL];
+        ASLR_UNROLL for (int i = 0; i < RPL; ++i) acc[i] = 0.0;
+        ASLR_UNROLL for (int c = 0; c < NU; ++c)
+          ASLR_UNROLL for (int i = 0; i < RPL; ++i) acc[i] += QuxL[c * NX + row(i)] * Kc[c];
+        // Vxx (unsymmetrised) with the state regularisation already on its diagonal: the average
+        // below leaves a diagonal entry d + xreg untouched
+        ASLR_UNROLL for (int i = 0; i < RPL; ++i)
+          if (row_ok(i)) VT[jj * NX + r0 + i] = (Qxx[i] - acc[i]) + oh_row[i] * xr;
+      }
+      const bool st_ok = writer && need && !failed && !(sp.debug & 1);
+      if (st_ok) {
+        double *Kout = a.kgain + tb * NU * NX;
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) Kout[c * NX + jj] = Kc[c];
+        if (j < NU) {
+          double kj = 0.0, qj = 0.0;
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) { kj += oh_u[c] * kv[c]; qj += oh_u[c] * qu[c]; }
+          a.kff[tb * NU + j] = kj;
+          a.qu[tb * NU + j] = qj;
+        }
+      }
+      wave_sync();
+      // ---- step 4: symmetrise (column jj of the symmetric Vxx = its row jj), gap term, publish Vx ----
+      double chk = 0.0;
+      ASLR_UNROLL for (int r = 0; r < NX; ++r) {
+        Pcol[r] = 0.5 * (VT[jj * NX + r] + VT[r * NX + jj]);
+        chk += fabs(Pcol[r]);
+      }
+      if (gaps_on) {
+        double vf = 0.0;
+        ASLR_UNROLL for (int r = 0; r < NX; ++r) vf += Pcol[r] * fg[r];
+        Vx_own += vf;
+        if (fddp) {
+          double fj = fg[0];
+          ASLR_UNROLL for (int r = 1; r < NX; ++r) if (r == jj) fj = fg[r];
+          dgf -= Vx_own * fj;
+          dqf += fj * vf;
+          if (st_ok) a.vxxf[tb * NX + jj] = vf;
+        }
+      }
+      chk += fabs(Vx_own);
+      // NaN / Inf / >= 1e30 anywhere in Vx, Vxx -> "backward_error" (the 1-norm of the column stands in
+      // for Crocoddyl's inf-norm test; they differ only for entries within 8x of 1e30)
+      if (__ballot(is_bad(chk)) & team_mask) failed = true;
+      if (sp.store_v && st_ok && !failed) {
+        a.vx[tb * NX + jj] = Vx_own;
+        double *o = a.vxx + tb * NX * NX;
+        ASLR_UNROLL for (int r = 0; r < NX; ++r) o[r * NX + jj] = Pcol[r];
+      }
+      VxL[jj] = Vx_own;
+      wave_sync();
+      ASLR_UNROLL for (int l = 0; l < NX; ++l) pvec[l] = VxL[l];
+    }
+    // ---- end of sweep: publish or regularise and retry ----
+    if (need) {
+      if (!failed) {
+        if (fddp) { // reduce the per-column gap terms over the team (one contributor per column)
+          if (!(col_valid && h == 0)) { dgf = 0.0; dqf = 0.0; }
+          ASLR_UNROLL for (int off = TEAM / 2; off > 0; off >>= 1) {
+            dgf += __shfl_xor(dgf, off);
+            dqf += __shfl_xor(dqf, off);
+          }
+        }
+        if (lt == 0) {
+          TF[ASLR_TF_STOP * B + b] = stop;
+          if (fddp) {
+            TF[ASLR_TF_DG * B + b] = d1 + dgf;
+            TF[ASLR_TF_DQ * B + b] = d2 + dqf;
+          }
+          TF[ASLR_TF_D1 * B + b] = d1;
+          TF[ASLR_TF_D2 * B + b] = d2;
+          TF[ASLR_TF_XREG * B + b] = xreg;
+          TI[ASLR_TI_STATUS * B + b] = status;
+        }
+        need = false;
+      } else {
+        status |= ASLR_ST_BACKWARD_ERR;
+        if (sp.standalone) {
+          if (lt == 0) TI[ASLR_TI_STATUS * B + b] = status;
+          need = false;
+        } else {
+          xreg *= sp.reg_incfactor;
+          if (xreg > sp.reg_max) xreg = sp.reg_max;
+          if (xreg == sp.reg_max) {
+            status |= ASLR_ST_REG_MAX;
+            if (lt == 0) {
+              TF[ASLR_TF_XREG * B + b] = xreg;
+              TI[ASLR_TI_STATUS * B + b] = status;
+              TI[ASLR_TI_DONE * B + b] = 1;
+            }
+            need = false;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NX, int NU, int HS>
+int launch_backward_t(const KArgs &k, const SolverDev &sd, const ModelLimits &lim, hipStream_t st) {
+  using C = BwdCfg<NX, NU, HS>;
+  const int blocks = (k.B + C::TPW - 1) / C::TPW;
+  const size_t lds = (size_t)C::TPW * C::LDS_TEAM * sizeof(double);
+  hipLaunchKernelGGL((backward_kernel<NX, NU, HS>), dim3(blocks), dim3(64), lds, st, k, sd, lim);
+  HIP_TRY(hipGetLastError());
+  return ASLR_OK;
+}
+
+} // namespace aslr

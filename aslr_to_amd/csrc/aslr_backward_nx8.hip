@@ -1,0 +1,11 @@
+// backward pass instantiated for nx = 8 (2-DoF SEA nu = 2, 2-DoF VSA nu = 4)
+#include "aslr_backward.inc.hpp"
+
+namespace aslr {
+int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, hipStream_t st) {
+  if (nu == 2) return hs == 2 ? launch_backward_t<8, 2, 2>(k, sd, lim, st) : launch_backward_t<8, 2, 1>(k, sd, lim, st);
+  if (nu == 4) return hs == 2 ? launch_backward_t<8, 4, 2>(k, sd, lim, st) : launch_backward_t<8, 4, 1>(k, sd, lim, st);
+  snprintf(err_buf(), kErrLen, "backward: unsupported (nx=8, nu=%d)", nu);
+  return ASLR_E_INVALID;
+}
+} // namespace aslr

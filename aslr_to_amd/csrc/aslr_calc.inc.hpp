@@ -1,0 +1,190 @@
+// aslr_calc.inc.hpp -- calc / calcDiff / dam_eval kernels (see aslr_kernels.md for the design)
+#pragma once
+#include "aslr_common.hpp"
+
+#ifndef ASLR_CALC_WAVES
+#define ASLR_CALC_WAVES 2 // waves per SIMD the register allocator must allow (6400 waves at B = 4096, T = 100)
+#endif
+
+namespace aslr {
+// =================================================================================================
+// calc / calcDiff
+// =================================================================================================
+constexpr int kChunk = 16;            // doubles per knot per LDS flush (one 128-B line)
+constexpr int kLdsStride = kChunk + 1; // odd stride: conflict-free ds_write_b64 across lanes
+
+
+template <int NJ, int DAM, bool DIFF, bool PLANAR>
+__global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int mode, double th_gaptol) {
+  constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
+  using RL = RecLayout<NJ, NU>;
+  constexpr int REC = RL::len;
+  __shared__ double sm[64 * kLdsStride];
+  __shared__ int act[64];
+
+  const int lane = threadIdx.x, t = blockIdx.y, B = a.B, T = a.T;
+  const int b0 = blockIdx.x * 64, bq = b0 + lane;
+  const bool valid = bq < B;
+  const int b = valid ? bq : B - 1;
+  const int32_t *TI = a.traj_i;
+
+  int acc = -1, recalc = 1, done = 0, feasible = 1;
+  if (mode & (kModeCommit | kModeSolver)) {
+    acc = TI[ASLR_TI_ACCEPTED * B + b];
+    if (!(mode & kModeCommit)) acc = -1;
+  }
+  if (mode & kModeSolver) {
+    recalc = TI[ASLR_TI_RECALC * B + b];
+    done = TI[ASLR_TI_DONE * B + b];
+    feasible = TI[ASLR_TI_FEASIBLE * B + b];
+  }
+  const size_t tb = (size_t)t * B + b;
+  const size_t TB1 = (size_t)(T + 1) * B, TB = (size_t)T * B;
+
+  // ---- x, u of this knot (from the accepted candidate when there is one) ----
+  double x[NX], u[NU];
+  {
+    const double *src = acc >= 0 ? a.xs_try + ((size_t)acc * TB1 + tb) * NX : a.xs + tb * NX;
+    ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = src[i];
+    if (acc >= 0 && valid) {
+      double *dst = a.xs + tb * NX;
+      ASLR_UNROLL for (int i = 0; i < NX; ++i) dst[i] = x[i];
+    }
+  }
+  if (t < T) {
+    const double *src = acc >= 0 ? a.us_try + ((size_t)acc * TB + tb) * NU : a.us + tb * NU;
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = src[i];
+    if (acc >= 0 && valid) {
+      double *dst = a.us + tb * NU;
+      ASLR_UNROLL for (int i = 0; i < NU; ++i) dst[i] = u[i];
+    }
+  } else {
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = 0.0;
+  }
+  const bool compute = valid && recalc && !done && !(mode & kModeNoCompute);
+  if (__ballot(compute) == 0ull) return; // wave-uniform
+
+  const DevDesc &D = *a.desc;
+  const DevModel &dm = D.models[a.node_model[t]];
+  const double *fref = a.frame_ref ? a.frame_ref + 12 * (size_t)b : nullptr;
+
+  double xnext[NX], cost = 0.0;
+  KnotDiff<NJ, NU> kd;
+  if (compute) {
+    using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
+    knot_eval<NJ, DAM, DIFF ? kEvalDiff : (kEvalDyn | kEvalCost), CH>(D, dm, fref, x, t < T ? u : nullptr, xnext, cost, DIFF ? &kd : nullptr);
+    double *xn = a.xnext + tb * NX;
+    ASLR_UNROLL for (int i = 0; i < NX; ++i) xn[i] = xnext[i];
+    a.cost[tb] = cost;
+    // gaps (SolverDDP::calcDiff): f[0] = x0 - xs[0]; f[t+1] = xnext_t - xs[t+1]
+    if ((mode & kModeSolver) && !feasible) {
+      double mx = 0.0;
+      if (t < T) {
+        const size_t tb1 = tb + B;
+        const double *src = acc >= 0 ? a.xs_try + ((size_t)acc * TB1 + tb1) * NX : a.xs + tb1 * NX;
+        double *g = a.gaps + tb1 * NX;
+        ASLR_UNROLL for (int i = 0; i < NX; ++i) {
+          const double f = xnext[i] - src[i];
+          g[i] = f;
+          mx = fmax(mx, fabs(f));
+        }
+      }
+      if (t == 0) {
+        const double *x0 = a.x0 + (size_t)b * NX;
+        double *g = a.gaps + tb * NX;
+        ASLR_UNROLL for (int i = 0; i < NX; ++i) {
+          const double f = x0[i] - x[i];
+          g[i] = f;
+          mx = fmax(mx, fabs(f));
+        }
+      }
+      if (mx >= th_gaptol) a.traj_i[ASLR_TI_GAPFLAG * B + b] = 1;
+    }
+  }
+  if constexpr (DIFF) {
+  // ---- stream the record out: 16 doubles per knot per flush, transposed through LDS ----
+  act[lane] = compute ? 1 : 0;
+  const double dt = dm.m.dt;
+  double *rec0 = a.deriv + ((size_t)t * B + b0) * REC;
+  static_for<0, REC / kChunk>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if (compute) {
+      static_for<0, kChunk>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        sm[lane * kLdsStride + i] = rec_elem<NJ, NU, c * kChunk + i>(kd, dt);
+      });
+    }
+    wave_sync();
+    ASLR_UNROLL for (int i = 0; i < kChunk / 2; ++i) {
+      const int idx = lane + 64 * i, k = idx >> 3, e = (idx & 7) * 2;
+      if (act[k]) {
+        double2 v2;
+        v2.x = sm[k * kLdsStride + e];
+        v2.y = sm[k * kLdsStride + e + 1];
+        *reinterpret_cast<double2 *>(rec0 + (size_t)k * REC + c * kChunk + e) = v2;
+      }
+    }
+    wave_sync();
+  });
+  }
+}
+
+// DAM-level evaluation of arbitrary points (aslr_dam_eval): dense continuous blocks, one lane per point
+template <int NJ, int DAM, bool PLANAR>
+__global__ void __launch_bounds__(64) dam_eval_kernel(const DevDesc *desc, int mi, const double *frame_ref, int n,
+                                                      const double *xin, const double *uin, double *xout,
+                                                      double *cost, double *Fx, double *Fu, double *Lx, double *Lu,
+                                                      double *Lxx, double *Lxu, double *Luu) {
+  constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu, NV = 2 * NJ;
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n) return;
+  const DevDesc &D = *desc;
+  const DevModel &dm = D.models[mi];
+  double x[NX], u[NU], xnext[NX], c, xo[NV];
+  ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = xin[(size_t)p * NX + i];
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = uin[(size_t)p * NU + i];
+  KnotDiff<NJ, NU> kd;
+  using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
+  knot_eval<NJ, DAM, kEvalDiff, CH>(D, dm, frame_ref, x, u, xnext, c, &kd, xo);
+  if (cost) cost[p] = c;
+  if (xout) {
+    ASLR_UNROLL for (int i = 0; i < NV; ++i) xout[(size_t)p * NV + i] = xo[i];
+  }
+  if (Fx) {
+    double *o = Fx + (size_t)p * NV * NX;
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+        o[i * NX + j] = kd.Aqq[i][j];
+        o[i * NX + NJ + j] = kd.Aqm[i][j];
+        o[i * NX + 2 * NJ + j] = kd.Aqv[i][j];
+        o[i * NX + 3 * NJ + j] = 0.0;
+        o[(NJ + i) * NX + j] = kd.Bk[i][j];
+        o[(NJ + i) * NX + NJ + j] = -kd.Bk[i][j];
+        o[(NJ + i) * NX + 2 * NJ + j] = 0.0;
+        o[(NJ + i) * NX + 3 * NJ + j] = 0.0;
+      }
+  }
+  if (Fu) {
+    double *o = Fu + (size_t)p * NV * NU;
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+      ASLR_UNROLL for (int j = 0; j < NU; ++j) { o[i * NU + j] = kd.Ful[i][j]; o[(NJ + i) * NU + j] = kd.Fum[i][j]; }
+  }
+  if (Lx) { ASLR_UNROLL for (int i = 0; i < NX; ++i) Lx[(size_t)p * NX + i] = kd.Lx[i]; }
+  if (Lu) { ASLR_UNROLL for (int i = 0; i < NU; ++i) Lu[(size_t)p * NU + i] = kd.Lu[i]; }
+  if (Lxx) {
+    double *o = Lxx + (size_t)p * NX * NX;
+    for (int i = 0; i < NX * NX; ++i) o[i] = 0.0;
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) o[i * NX + j] = kd.Lqq[i][j];
+    ASLR_UNROLL for (int i = 0; i < NX; ++i) o[i * NX + i] += kd.Lxxd[i];
+  }
+  if (Lxu) { for (int i = 0; i < NX * NU; ++i) Lxu[(size_t)p * NX * NU + i] = 0.0; }
+  if (Luu) {
+    double *o = Luu + (size_t)p * NU * NU;
+    for (int i = 0; i < NU * NU; ++i) o[i] = 0.0;
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) o[i * NU + i] = kd.Luud[i];
+  }
+}
+
+
+} // namespace aslr

@@ -1,0 +1,54 @@
+// calc / calcDiff kernels instantiated for nj = 2 (3-D and planar chain paths)
+#include "aslr_calc.inc.hpp"
+
+namespace aslr {
+
+int launch_calc_nj2(const KArgs &k, int dam, bool diff, int mode, double th_gaptol, hipStream_t st) {
+  dim3 grid((k.B + 63) / 64, k.T + 1), block(64);
+  if (dam == ASLR_DAM_SEA) {
+    if (k.planar) {
+      if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, true, true>), grid, block, 0, st, k, mode, th_gaptol);
+      else hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, false, true>), grid, block, 0, st, k, mode, th_gaptol);
+    } else {
+      if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, true, false>), grid, block, 0, st, k, mode, th_gaptol);
+      else hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, false, false>), grid, block, 0, st, k, mode, th_gaptol);
+    }
+    HIP_TRY(hipGetLastError());
+    return ASLR_OK;
+  }
+  if (dam == ASLR_DAM_VSA) {
+    if (k.planar) {
+      if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, true, true>), grid, block, 0, st, k, mode, th_gaptol);
+      else hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, false, true>), grid, block, 0, st, k, mode, th_gaptol);
+    } else {
+      if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, true, false>), grid, block, 0, st, k, mode, th_gaptol);
+      else hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, false, false>), grid, block, 0, st, k, mode, th_gaptol);
+    }
+    HIP_TRY(hipGetLastError());
+    return ASLR_OK;
+  }
+  snprintf(err_buf(), kErrLen, "calc: unsupported (nj=2, dam=%d)", dam);
+  return ASLR_E_INVALID;
+}
+
+int launch_dam_eval_nj2(const KArgs &k, int dam, int mi, int n, const double *x, const double *u, double *xout,
+                        double *cost, double *Fx, double *Fu, double *Lx, double *Lu, double *Lxx, double *Lxu,
+                        double *Luu, hipStream_t st) {
+  dim3 grid((n + 63) / 64), block(64);
+  if (dam == ASLR_DAM_SEA) {
+    if (k.planar) hipLaunchKernelGGL((dam_eval_kernel<2, ASLR_DAM_SEA, true>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, xout, cost, Fx, Fu, Lx, Lu, Lxx, Lxu, Luu);
+    else hipLaunchKernelGGL((dam_eval_kernel<2, ASLR_DAM_SEA, false>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, xout, cost, Fx, Fu, Lx, Lu, Lxx, Lxu, Luu);
+    HIP_TRY(hipGetLastError());
+    return ASLR_OK;
+  }
+  if (dam == ASLR_DAM_VSA) {
+    if (k.planar) hipLaunchKernelGGL((dam_eval_kernel<2, ASLR_DAM_VSA, true>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, xout, cost, Fx, Fu, Lx, Lu, Lxx, Lxu, Luu);
+    else hipLaunchKernelGGL((dam_eval_kernel<2, ASLR_DAM_VSA, false>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, xout, cost, Fx, Fu, Lx, Lu, Lxx, Lxu, Luu);
+    HIP_TRY(hipGetLastError());
+    return ASLR_OK;
+  }
+  snprintf(err_buf(), kErrLen, "dam_eval: unsupported (nj=2, dam=%d)", dam);
+  return ASLR_E_INVALID;
+}
+
+} // namespace aslr

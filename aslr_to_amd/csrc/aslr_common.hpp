@@ -1,0 +1,82 @@
+// aslr_common.hpp -- shared by the per-kernel translation units of libaslr_to_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "aslr_device.hpp"
+
+namespace aslr {
+
+char *err_buf();            // thread-local error string (aslr_last_error)
+constexpr int kErrLen = 512;
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      snprintf(aslr::err_buf(), aslr::kErrLen, "%s -> %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+               __LINE__);                                                                           \
+      return ASLR_E_HIP;                                                                            \
+    }                                                                                               \
+  } while (0)
+
+constexpr int rec_len_c(int nx, int nu) { return (2 * nx * nx + 2 * nx * nu + nu * nu + nx + nu + 15) / 16 * 16; }
+
+// kernel argument block: device pointers into the workspace
+struct KArgs {
+  const DevDesc *desc;
+  const int32_t *node_model;
+  const double *x0;
+  const double *frame_ref; // nullable
+  double *xs, *us, *xnext, *cost, *deriv, *gaps, *kgain, *kff, *qu, *vx, *vxx, *xs_try, *us_try, *vxxf;
+  double *traj_f;
+  int32_t *traj_i;
+  int32_t B, T;
+  int32_t planar; // the chain qualifies for the planar dynamics path (DevDesc::planar.ok)
+};
+
+// solver parameters by value
+struct SolverDev {
+  int32_t solver, fixed_iterations;
+  double th_stop, th_grad, th_gaptol, th_stepdec, th_stepinc, th_acceptstep, th_acceptnegstep;
+  double reg_min, reg_max, reg_incfactor, reg_decfactor;
+  int32_t boxqp_maxiter;
+  double boxqp_th_acceptstep, boxqp_th_grad, boxqp_reg;
+  int32_t standalone; // 1: API-level single pass (no retry, no solver-state updates)
+  int32_t store_v;    // 1: write VX / VXX
+  int32_t debug;      // ASLR_DEBUG bits (timing experiments only): 1 no gain stores, 2 no record loads
+};
+
+// control limits of the (at most ASLR_MAX_MODELS) action models, passed by value so the backward loop
+// never chases model pointers
+struct ModelLimits {
+  int32_t has[ASLR_MAX_MODELS];
+  double lb[ASLR_MAX_MODELS][ASLR_MAX_NU], ub[ASLR_MAX_MODELS][ASLR_MAX_NU];
+};
+
+__device__ __forceinline__ bool is_bad(double v) { return isnan(v) || isinf(v) || v >= 1e30; }
+
+// calc_kernel mode bits
+constexpr int kModeCommit = 1;    // copy the accepted candidate XS_TRY/US_TRY[acc] into XS/US
+constexpr int kModeSolver = 2;    // honour RECALC/DONE flags and compute gaps
+constexpr int kModeNoCompute = 4;
+
+// launchers, one translation unit per (kernel family, size)
+int launch_calc_nj2(const KArgs &k, int dam, bool diff, int mode, double th_gaptol, hipStream_t st);
+int launch_calc_nj7(const KArgs &k, int dam, bool diff, int mode, double th_gaptol, hipStream_t st);
+int launch_dam_eval_nj2(const KArgs &k, int dam, int mi, int n, const double *x, const double *u, double *xout,
+                        double *cost, double *Fx, double *Fu, double *Lx, double *Lu, double *Lxx, double *Lxu,
+                        double *Luu, hipStream_t st);
+int launch_dam_eval_nj7(const KArgs &k, int dam, int mi, int n, const double *x, const double *u, double *xout,
+                        double *cost, double *Fx, double *Fu, double *Lx, double *Lu, double *Lxx, double *Lxu,
+                        double *Luu, hipStream_t st);
+int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, hipStream_t st);
+int launch_backward_nx28(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, hipStream_t st);
+int launch_forward_nj2(const KArgs &k, int dam, const SolverDev &sd, hipStream_t st);
+int launch_forward_nj7(const KArgs &k, int dam, const SolverDev &sd, hipStream_t st);
+
+} // namespace aslr

@@ -23,14 +23,57 @@ namespace aslr {
 #define ASLR_DEV __device__ __forceinline__
 #define ASLR_UNROLL _Pragma("unroll")
 
+// Ordering point for LDS traffic inside ONE wavefront (every block of these kernels is a single
+// wave): the hardware executes a wave's LDS instructions in order, so all that is needed is that the
+// compiler does not move LDS accesses across this point.  Unlike __syncthreads() it does not drain
+// vmcnt, so global prefetches and streaming stores stay in flight across it.
+ASLR_DEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sin/cos for joint angles: Cody-Waite reduction by pi/2 (33 + 53 bits of pi/2, exact for
+// |x| < ~1e5) and the fdlibm kernel polynomials; < 1 ulp there.  Larger arguments take the library
+// path.  (ocml's sincos carries the full Payne-Hanek reduction inline: ~6x the instructions.)
+ASLR_DEV void sincos_fast(double x, double *sn, double *cs) {
+  if (!(fabs(x) < 1.0e5)) { sincos(x, sn, cs); return; }
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  const double r = fma(-fn, 1.57079632673412561417e+00, x);
+  const double y = r - fn * 6.07710050650619224932e-11;
+  const double z = y * y;
+  // kernel sin
+  const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                    z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double ks = y + (z * y) * (-1.66666666666666324348e-01 + z * rs);
+  // kernel cos
+  const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double kc = w + (((1.0 - w) - hz) + z * rc);
+  const int n = (int)fn & 3;
+  const double s0 = (n & 1) ? kc : ks, c0 = (n & 1) ? ks : kc;
+  *sn = (n & 2) ? -s0 : s0;
+  *cs = ((n + 1) & 2) ? -c0 : c0;
+}
+
 // Device-side model: the ABI struct plus host-precomputed inverse of the motor inertia.
 struct DevModel {
   aslr_model_t m;
   double Binv[ASLR_MAX_NJ * ASLR_MAX_NJ];
 };
+// Planar restatement of the chain (valid when `ok`): every joint axis is +z and every joint
+// placement rotates about z.  Filled on the host at problem creation.
+struct PlanarChain {
+  int32_t ok, _pad;
+  double gx, gy;
+  double cphi[ASLR_MAX_NJ], sphi[ASLR_MAX_NJ], px[ASLR_MAX_NJ], py[ASLR_MAX_NJ], pz[ASLR_MAX_NJ];
+  double m[ASLR_MAX_NJ], cx[ASLR_MAX_NJ], cy[ASLR_MAX_NJ], izz[ASLR_MAX_NJ];
+};
 struct DevDesc {
   aslr_chain_t chain;
   DevModel models[ASLR_MAX_MODELS];
+  PlanarChain planar;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -83,7 +126,7 @@ ASLR_DEV SV sv_zero() { return SV{V3{0, 0, 0}, V3{0, 0, 0}}; }
 // Rodrigues rotation about a unit axis (JointModelRevoluteUnaligned)
 ASLR_DEV M3 axis_angle(V3 ax, double q) {
   double s, c;
-  sincos(q, &s, &c);
+  sincos_fast(q, &s, &c);
   const double v = 1.0 - c;
   M3 R;
   R.a[0] = ax.x * ax.x * v + c;        R.a[1] = ax.x * ax.y * v - ax.z * s; R.a[2] = ax.x * ax.z * v + ax.y * s;
@@ -250,6 +293,40 @@ ASLR_DEV void chol_solve(const double (&L)[N][N], double (&b)[N]) {
     b[i] = s / L[i][i];
   }
 }
+// Cholesky with reciprocal pivots: L (lower, in place) and rinv[i] = 1 / L[i][i]; true on a
+// non-positive pivot.  The triangular solves below multiply by rinv instead of dividing.
+template <int N>
+ASLR_DEV bool chol_r(double (&A)[N][N], double (&rinv)[N]) {
+  bool bad = false;
+  ASLR_UNROLL for (int j = 0; j < N; ++j) {
+    double d = A[j][j];
+    ASLR_UNROLL for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+    if (!(d > 0.0)) bad = true;
+    d = sqrt(d);
+    A[j][j] = d;
+    rinv[j] = 1.0 / d;
+    ASLR_UNROLL for (int i = j + 1; i < N; ++i) {
+      double s = A[i][j];
+      ASLR_UNROLL for (int k = 0; k < j; ++k) s -= A[i][k] * A[j][k];
+      A[i][j] = s * rinv[j];
+    }
+  }
+  return bad;
+}
+template <int N>
+ASLR_DEV void chol_solve_r(const double (&L)[N][N], const double (&rinv)[N], double (&b)[N]) {
+  ASLR_UNROLL for (int i = 0; i < N; ++i) {
+    double s = b[i];
+    ASLR_UNROLL for (int k = 0; k < i; ++k) s -= L[i][k] * b[k];
+    b[i] = s * rinv[i];
+  }
+  ASLR_UNROLL for (int i = N - 1; i >= 0; --i) {
+    double s = b[i];
+    ASLR_UNROLL for (int k = i + 1; k < N; ++k) s -= L[k][i] * b[k];
+    b[i] = s * rinv[i];
+  }
+}
+
 template <int N>
 ASLR_DEV void spd_inverse(const double (&A)[N][N], double (&Ainv)[N][N]) {
   double L[N][N];
@@ -265,21 +342,12 @@ ASLR_DEV void spd_inverse(const double (&A)[N][N], double (&Ainv)[N][N]) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// chain dynamics
+// chain dynamics, generic 3-D path
 // ---------------------------------------------------------------------------------------------
 template <int NJ>
 struct Kin { // forward kinematics shared by everything at one q
   SE3d liMi[NJ];
 };
-
-template <int NJ>
-ASLR_DEV void joint_placements(const aslr_chain_t &c, const double *q, Kin<NJ> &k) {
-  ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
-    const M3 Rj = axis_angle(v3(c.axis[i]), q[i]);
-    k.liMi[i].R = mul(m3(c.joint_R[i]), Rj);
-    k.liMi[i].p = v3(c.joint_p[i]);
-  }
-}
 
 // RNEA(q, v, a) with gravity; keeps what the tangent passes need when KEEP is set.
 template <int NJ>
@@ -315,70 +383,254 @@ ASLR_DEV void rnea(const aslr_chain_t &c, const Kin<NJ> &k, const double *v, con
   }
 }
 
-// joint-space inertia: column j = RNEA(q, 0, e_j) without gravity; symmetrised like the Python
-// binding's data.M
+// Chain policy: generic fixed-base revolute chain in 3-D.
 template <int NJ>
-ASLR_DEV void crba(const aslr_chain_t &c, const Kin<NJ> &k, double (&M)[NJ][NJ]) {
-  ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
-    SV ap = sv_zero();
-    SV f[NJ];
+struct Chain3D {
+  const aslr_chain_t &c;
+  Kin<NJ> kin;
+  RneaWs<NJ> ws;
+  SE3d oMi[NJ];
+  ASLR_DEV explicit Chain3D(const DevDesc &D) : c(D.chain) {}
+
+  ASLR_DEV void setup(const double *q) {
     ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
-      if (i < j) { f[i] = sv_zero(); continue; }
-      SV ai = (i == j) ? sv_zero() : motion_actinv(k.liMi[i], ap);
-      if (i == j) ai.ang = v3(c.axis[i]);
-      f[i] = inertia_mul(c.mass[i], v3(c.com[i]), m3(c.inertia[i]), ai);
+      const M3 Rj = axis_angle(v3(c.axis[i]), q[i]);
+      kin.liMi[i].R = mul(m3(c.joint_R[i]), Rj);
+      kin.liMi[i].p = v3(c.joint_p[i]);
+    }
+  }
+  // data.nle = RNEA(q, v, 0)
+  ASLR_DEV void nle(const double *v, double *out) {
+    double zero[NJ];
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) zero[i] = 0.0;
+    rnea<NJ, false>(c, kin, v, zero, v3(c.gravity), out, ws);
+  }
+  // joint-space inertia: column j = RNEA(q, 0, e_j) without gravity; symmetrised like the Python
+  // binding's data.M
+  ASLR_DEV void mass(double (&M)[NJ][NJ]) {
+    ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+      SV ap = sv_zero();
+      SV f[NJ];
+      ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+        if (i < j) { f[i] = sv_zero(); continue; }
+        SV ai = (i == j) ? sv_zero() : motion_actinv(kin.liMi[i], ap);
+        if (i == j) ai.ang = v3(c.axis[i]);
+        f[i] = inertia_mul(c.mass[i], v3(c.com[i]), m3(c.inertia[i]), ai);
+        ap = ai;
+      }
+      ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
+        M[i][j] = dot(v3(c.axis[i]), f[i].ang);
+        if (i > 0) f[i - 1] = f[i - 1] + force_act(kin.liMi[i], f[i]);
+      }
+    }
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+      ASLR_UNROLL for (int j = i + 1; j < NJ; ++j) {
+        const double s = 0.5 * (M[i][j] + M[j][i]);
+        M[i][j] = s;
+        M[j][i] = s;
+      }
+  }
+  // computeRNEADerivatives(q, v, a) by forward-mode differentiation of the recursion (one
+  // direction per column): dq[i][j] = dtau_i/dq_j, dv[i][j] = dtau_i/dv_j.
+  ASLR_DEV void rnea_derivatives(const double *v, const double *a, double (&dq)[NJ][NJ], double (&dv)[NJ][NJ]) {
+    double tau[NJ];
+    rnea<NJ, true>(c, kin, v, a, v3(c.gravity), tau, ws);
+    ASLR_UNROLL for (int kind = 0; kind < 2; ++kind) {
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+        const SV Sj = SV{V3{0, 0, 0}, v3(c.axis[j])};
+        SV dvp = sv_zero(), dap = sv_zero();
+        SV df[NJ];
+        ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+          if (i < j) { df[i] = sv_zero(); continue; } // nothing upstream of joint j moves
+          SV dvi = (i == j) ? sv_zero() : motion_actinv(kin.liMi[i], dvp);
+          SV dai = (i == j) ? sv_zero() : motion_actinv(kin.liMi[i], dap);
+          if (i == j) {
+            if (kind == 0) { dvi = crm(ws.Xv[i], Sj); dai = crm(ws.Xa[i], Sj); }
+            else { dvi = Sj; dai = crm(ws.v[i], Sj); }
+          }
+          dai = dai + crm(dvi, ws.vJ[i]);
+          const V3 com = v3(c.com[i]);
+          const M3 I = m3(c.inertia[i]);
+          df[i] = inertia_mul(c.mass[i], com, I, dai) + crf(dvi, ws.h[i]) +
+                  crf(ws.v[i], inertia_mul(c.mass[i], com, I, dvi));
+          dvp = dvi;
+          dap = dai;
+        }
+        ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
+          const double val = dot(v3(c.axis[i]), df[i].ang);
+          if (kind == 0) dq[i][j] = val; else dv[i][j] = val;
+          if (i > 0) {
+            df[i - 1] = df[i - 1] + force_act(kin.liMi[i], df[i]);
+            if (kind == 0 && i == j) df[i - 1] = df[i - 1] + force_act(kin.liMi[i], crf(Sj, ws.F[i]));
+          }
+        }
+      }
+    }
+  }
+  // world placement of joint fj (runtime index); also fills oMi for jac_col
+  ASLR_DEV SE3d joint_world(int fj) {
+    oMi[0] = kin.liMi[0];
+    ASLR_UNROLL for (int i = 1; i < NJ; ++i) oMi[i] = se3_mul(oMi[i - 1], kin.liMi[i]);
+    SE3d r = oMi[0];
+    ASLR_UNROLL for (int i = 1; i < NJ; ++i) if (i == fj) r = oMi[i];
+    return r;
+  }
+  // LOCAL frame Jacobian column j: (oMf^-1 oMj).act(S_j)
+  ASLR_DEV SV jac_col(int j, const SE3d &oMf) const {
+    SE3d fMj;
+    fMj.R = mulTN(oMf.R, oMi[j].R);
+    fMj.p = mulT(oMf.R, oMi[j].p - oMf.p);
+    return motion_act(fMj, SV{V3{0, 0, 0}, v3(c.axis[j])});
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// chain dynamics, planar path: every joint axis is +z of its frame and every joint placement is a
+// rotation about z, so only (omega_z, v_x, v_y) / (n_z, f_x, f_y) carry the dynamics.  Same
+// recursions as above on 3-vectors; offsets and gravity along z cannot load the joints.
+// ---------------------------------------------------------------------------------------------
+struct PV { double w, x, y; };      // planar motion (w: angular z) or force (w: moment z)
+struct PX { double c, s, px, py; }; // liMi: x_parent = Rz(c, s) x_child + (px, py)
+
+ASLR_DEV PV operator+(PV a, PV b) { return PV{a.w + b.w, a.x + b.x, a.y + b.y}; }
+ASLR_DEV PV pv_zero() { return PV{0.0, 0.0, 0.0}; }
+ASLR_DEV PV p_actinv(PX X, PV m) { // motion parent -> child
+  const double vx = m.x - X.py * m.w, vy = m.y + X.px * m.w;
+  return PV{m.w, X.c * vx + X.s * vy, X.c * vy - X.s * vx};
+}
+ASLR_DEV PV p_fact(PX X, PV f) { // force child -> parent
+  const double lx = X.c * f.x - X.s * f.y, ly = X.s * f.x + X.c * f.y;
+  return PV{f.w + X.px * ly - X.py * lx, lx, ly};
+}
+ASLR_DEV PV p_crm(PV a, PV b) { return PV{0.0, b.w * a.y - a.w * b.y, a.w * b.x - b.w * a.x}; }
+ASLR_DEV PV p_crf(PV a, PV f) { return PV{a.x * f.y - a.y * f.x, -a.w * f.y, a.w * f.x}; }
+ASLR_DEV PV p_inertia(double m, double cx, double cy, double izz, PV v) {
+  const double lx = m * (v.x - cy * v.w), ly = m * (v.y + cx * v.w);
+  return PV{izz * v.w + cx * ly - cy * lx, lx, ly};
+}
+
+template <int NJ>
+struct ChainPlanar {
+  const PlanarChain &pc;
+  PX X[NJ];
+  PV v_[NJ], h_[NJ], F_[NJ], Xv_[NJ], Xa_[NJ];
+  double qd_[NJ];
+  double cT[NJ], sT[NJ], Px[NJ], Py[NJ]; // world angle / position of each joint frame
+  ASLR_DEV explicit ChainPlanar(const DevDesc &D) : pc(D.planar) {}
+
+  ASLR_DEV void setup(const double *q) {
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+      double s, c;
+      sincos_fast(q[i], &s, &c);
+      // Rz(phi_i) Rz(q_i)
+      X[i] = PX{pc.cphi[i] * c - pc.sphi[i] * s, pc.sphi[i] * c + pc.cphi[i] * s, pc.px[i], pc.py[i]};
+    }
+  }
+  template <bool KEEP>
+  ASLR_DEV void rnea_(const double *v, const double *a, double *tau) {
+    PV vp = pv_zero(), ap = PV{0.0, -pc.gx, -pc.gy};
+    PV f[NJ];
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+      const PV Xv = p_actinv(X[i], vp);
+      PV vi = Xv;
+      vi.w += v[i];
+      const PV Xa = p_actinv(X[i], ap);
+      PV ai = Xa + p_crm(vi, PV{v[i], 0.0, 0.0});
+      ai.w += a[i];
+      const PV h = p_inertia(pc.m[i], pc.cx[i], pc.cy[i], pc.izz[i], vi);
+      f[i] = p_inertia(pc.m[i], pc.cx[i], pc.cy[i], pc.izz[i], ai) + p_crf(vi, h);
+      if (KEEP) { v_[i] = vi; h_[i] = h; Xv_[i] = Xv; Xa_[i] = Xa; qd_[i] = v[i]; }
+      vp = vi;
       ap = ai;
     }
     ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
-      M[i][j] = dot(v3(c.axis[i]), f[i].ang);
-      if (i > 0) f[i - 1] = f[i - 1] + force_act(k.liMi[i], f[i]);
+      tau[i] = f[i].w;
+      if (i > 0) f[i - 1] = f[i - 1] + p_fact(X[i], f[i]);
+      if (KEEP) F_[i] = f[i];
     }
   }
-  ASLR_UNROLL for (int i = 0; i < NJ; ++i)
-    ASLR_UNROLL for (int j = i + 1; j < NJ; ++j) {
-      const double s = 0.5 * (M[i][j] + M[j][i]);
-      M[i][j] = s;
-      M[j][i] = s;
-    }
-}
-
-// computeRNEADerivatives by forward-mode differentiation of the recursion (one direction per
-// column): dtau_dq[i][j], dtau_dv[i][j].  `w` comes from rnea<KEEP=true>(q, v, a).
-template <int NJ>
-ASLR_DEV void rnea_derivatives(const aslr_chain_t &c, const Kin<NJ> &k, const RneaWs<NJ> &w,
-                               double (&dq)[NJ][NJ], double (&dv)[NJ][NJ]) {
-  ASLR_UNROLL for (int kind = 0; kind < 2; ++kind) {
+  ASLR_DEV void nle(const double *v, double *out) {
+    double zero[NJ];
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) zero[i] = 0.0;
+    rnea_<false>(v, zero, out);
+  }
+  ASLR_DEV void mass(double (&M)[NJ][NJ]) {
     ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
-      const SV Sj = SV{V3{0, 0, 0}, v3(c.axis[j])};
-      SV dvp = sv_zero(), dap = sv_zero();
-      SV df[NJ];
+      PV ap = pv_zero();
+      PV f[NJ];
       ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
-        if (i < j) { df[i] = sv_zero(); continue; } // nothing upstream of joint j moves
-        SV dvi = (i == j) ? sv_zero() : motion_actinv(k.liMi[i], dvp);
-        SV dai = (i == j) ? sv_zero() : motion_actinv(k.liMi[i], dap);
-        if (i == j) {
-          if (kind == 0) { dvi = crm(w.Xv[i], Sj); dai = crm(w.Xa[i], Sj); }
-          else { dvi = Sj; dai = crm(w.v[i], Sj); }
-        }
-        dai = dai + crm(dvi, w.vJ[i]);
-        const V3 com = v3(c.com[i]);
-        const M3 I = m3(c.inertia[i]);
-        df[i] = inertia_mul(c.mass[i], com, I, dai) + crf(dvi, w.h[i]) +
-                crf(w.v[i], inertia_mul(c.mass[i], com, I, dvi));
-        dvp = dvi;
-        dap = dai;
+        if (i < j) { f[i] = pv_zero(); continue; }
+        const PV ai = (i == j) ? PV{1.0, 0.0, 0.0} : p_actinv(X[i], ap);
+        f[i] = p_inertia(pc.m[i], pc.cx[i], pc.cy[i], pc.izz[i], ai);
+        ap = ai;
       }
       ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
-        const double val = dot(v3(c.axis[i]), df[i].ang);
-        if (kind == 0) dq[i][j] = val; else dv[i][j] = val;
-        if (i > 0) {
-          df[i - 1] = df[i - 1] + force_act(k.liMi[i], df[i]);
-          if (kind == 0 && i == j) df[i - 1] = df[i - 1] + force_act(k.liMi[i], crf(Sj, w.F[i]));
+        M[i][j] = f[i].w;
+        if (i > 0) f[i - 1] = f[i - 1] + p_fact(X[i], f[i]);
+      }
+    }
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+      ASLR_UNROLL for (int j = i + 1; j < NJ; ++j) {
+        const double s = 0.5 * (M[i][j] + M[j][i]);
+        M[i][j] = s;
+        M[j][i] = s;
+      }
+  }
+  ASLR_DEV void rnea_derivatives(const double *v, const double *a, double (&dq)[NJ][NJ], double (&dv)[NJ][NJ]) {
+    double tau[NJ];
+    rnea_<true>(v, a, tau);
+    const PV S = PV{1.0, 0.0, 0.0};
+    ASLR_UNROLL for (int kind = 0; kind < 2; ++kind) {
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+        PV dvp = pv_zero(), dap = pv_zero();
+        PV df[NJ];
+        ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+          if (i < j) { df[i] = pv_zero(); continue; }
+          PV dvi = (i == j) ? pv_zero() : p_actinv(X[i], dvp);
+          PV dai = (i == j) ? pv_zero() : p_actinv(X[i], dap);
+          if (i == j) {
+            if (kind == 0) { dvi = p_crm(Xv_[i], S); dai = p_crm(Xa_[i], S); }
+            else { dvi = S; dai = p_crm(v_[i], S); }
+          }
+          dai = dai + p_crm(dvi, PV{qd_[i], 0.0, 0.0});
+          df[i] = p_inertia(pc.m[i], pc.cx[i], pc.cy[i], pc.izz[i], dai) + p_crf(dvi, h_[i]) +
+                  p_crf(v_[i], p_inertia(pc.m[i], pc.cx[i], pc.cy[i], pc.izz[i], dvi));
+          dvp = dvi;
+          dap = dai;
+        }
+        ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
+          if (kind == 0) dq[i][j] = df[i].w; else dv[i][j] = df[i].w;
+          if (i > 0) {
+            df[i - 1] = df[i - 1] + p_fact(X[i], df[i]);
+            if (kind == 0 && i == j) df[i - 1] = df[i - 1] + p_fact(X[i], p_crf(S, F_[i]));
+          }
         }
       }
     }
   }
-}
+  ASLR_DEV SE3d joint_world(int fj) {
+    cT[0] = X[0].c; sT[0] = X[0].s; Px[0] = X[0].px; Py[0] = X[0].py;
+    ASLR_UNROLL for (int i = 1; i < NJ; ++i) {
+      cT[i] = cT[i - 1] * X[i].c - sT[i - 1] * X[i].s;
+      sT[i] = sT[i - 1] * X[i].c + cT[i - 1] * X[i].s;
+      Px[i] = Px[i - 1] + (cT[i - 1] * X[i].px - sT[i - 1] * X[i].py);
+      Py[i] = Py[i - 1] + (sT[i - 1] * X[i].px + cT[i - 1] * X[i].py);
+    }
+    double c = cT[0], s = sT[0], x = Px[0], y = Py[0], z = pc.pz[0];
+    ASLR_UNROLL for (int i = 1; i < NJ; ++i) if (i == fj) { c = cT[i]; s = sT[i]; x = Px[i]; y = Py[i]; z = pc.pz[i]; }
+    SE3d r;
+    r.R.a[0] = c; r.R.a[1] = -s; r.R.a[2] = 0.0;
+    r.R.a[3] = s; r.R.a[4] = c;  r.R.a[5] = 0.0;
+    r.R.a[6] = 0.0; r.R.a[7] = 0.0; r.R.a[8] = 1.0;
+    r.p = V3{x, y, z};
+    return r;
+  }
+  ASLR_DEV SV jac_col(int j, const SE3d &oMf) const {
+    // joint j turns the frame about the world z axis through (Px[j], Py[j])
+    const V3 lin = V3{-(oMf.p.y - Py[j]), oMf.p.x - Px[j], 0.0};
+    return SV{mulT(oMf.R, lin), V3{oMf.R.a[6], oMf.R.a[7], oMf.R.a[8]}};
+  }
+};
 
 // ---------------------------------------------------------------------------------------------
 // knot-level results
@@ -398,14 +650,140 @@ template <int NJ, int DAM> struct ModelDims {
   static constexpr int nu = DAM == ASLR_DAM_VSA ? 2 * NJ : NJ;
 };
 
-// calc (+ calcDiff when DIFF): x[4NJ], u[NU] -> xnext, cost (+ compact derivatives).
+// SE(3) log of the frame-placement residual with the sin/cos of its angle shared between
+// log6, Jlog3 and Jlog6 (same formulas as log6()/jlog6() above).
+struct Log6 {
+  double r[6], t, st, ct;
+  V3 w;
+};
+ASLR_DEV void log6_shared(const SE3d &M, Log6 &o) {
+  // log3 (same branches as log3() above) with sin(theta), cos(theta) taken from the trace:
+  // cos(theta) = (tr - 1) / 2 and sin(theta) = sqrt((1 - c)(1 + c)) for theta = acos(c) in [0, pi]
+  const M3 &R = M.R;
+  double tr = R.a[0] + R.a[4] + R.a[8], theta;
+  if (tr >= 3.0) { tr = 3.0; theta = 0.0; }
+  else if (tr <= -1.0) { tr = -1.0; theta = kPi; }
+  else theta = acos((tr - 1.0) / 2.0);
+  o.ct = (tr - 1.0) / 2.0;
+  o.st = sqrt((1.0 - o.ct) * (1.0 + o.ct));
+  if (theta >= kPi - 1e-2) {
+    const double cphi = -(tr - 1.0) / 2.0;
+    const double beta = theta * theta / (1.0 + cphi);
+    const double t0 = (R.a[0] + cphi) * beta, t1 = (R.a[4] + cphi) * beta, t2 = (R.a[8] + cphi) * beta;
+    o.w.x = (R.a[7] > R.a[5] ? 1.0 : -1.0) * (t0 > 0.0 ? sqrt(t0) : 0.0);
+    o.w.y = (R.a[2] > R.a[6] ? 1.0 : -1.0) * (t1 > 0.0 ? sqrt(t1) : 0.0);
+    o.w.z = (R.a[3] > R.a[1] ? 1.0 : -1.0) * (t2 > 0.0 ? sqrt(t2) : 0.0);
+  } else {
+    const double t = ((theta > kTaylorPrec) ? theta / o.st : 1.0) / 2.0;
+    o.w.x = t * (R.a[7] - R.a[5]);
+    o.w.y = t * (R.a[2] - R.a[6]);
+    o.w.z = t * (R.a[3] - R.a[1]);
+  }
+  o.t = theta;
+  const double t = o.t, t2 = t * t;
+  double alpha, beta;
+  if (t < kTaylorPrec) {
+    alpha = 1.0 - t2 / 12.0 - t2 * t2 / 720.0;
+    beta = 1.0 / 12.0 + t2 / 720.0;
+  } else {
+    alpha = t * o.st / (2.0 * (1.0 - o.ct));
+    beta = 1.0 / t2 - o.st / (2.0 * t * (1.0 - o.ct));
+  }
+  const V3 wxp = cross(o.w, M.p);
+  const double wp = dot(o.w, M.p);
+  o.r[0] = alpha * M.p.x - 0.5 * wxp.x + beta * wp * o.w.x;
+  o.r[1] = alpha * M.p.y - 0.5 * wxp.y + beta * wp * o.w.y;
+  o.r[2] = alpha * M.p.z - 0.5 * wxp.z + beta * wp * o.w.z;
+  o.r[3] = o.w.x; o.r[4] = o.w.y; o.r[5] = o.w.z;
+}
+ASLR_DEV void jlog6_shared(const SE3d &M, const Log6 &L, M3 &A, M3 &Bm) {
+  const double t = L.t, t2 = t * t, st = L.st, ct = L.ct;
+  const V3 w = L.w;
+  double beta, bdot, alpha3, diag3;
+  if (t < kTaylorPrec) {
+    beta = 1.0 / 12.0 + t2 / 720.0;
+    bdot = 1.0 / 360.0;
+    alpha3 = 1.0 / 12.0 + t2 / 720.0;
+    diag3 = 0.5 * (2.0 - t2 / 6.0);
+  } else {
+    const double tinv = 1.0 / t, t2inv = tinv * tinv;
+    const double inv_2_2ct = 1.0 / (2.0 * (1.0 - ct));
+    beta = t2inv - st * tinv * inv_2_2ct;
+    bdot = -2.0 * t2inv * t2inv + (1.0 + st * tinv) * t2inv * inv_2_2ct;
+    const double st_1mct = st / (1.0 - ct);
+    alpha3 = 1.0 / t2 - st_1mct / (2.0 * t);
+    diag3 = 0.5 * (t * st_1mct);
+  }
+  const double wv[3] = {w.x, w.y, w.z};
+  ASLR_UNROLL for (int i = 0; i < 3; ++i)
+    ASLR_UNROLL for (int j = 0; j < 3; ++j) A.a[3 * i + j] = alpha3 * wv[i] * wv[j];
+  A.a[0] += diag3; A.a[4] += diag3; A.a[8] += diag3;
+  A.a[1] -= 0.5 * w.z; A.a[2] += 0.5 * w.y;
+  A.a[3] += 0.5 * w.z; A.a[5] -= 0.5 * w.x;
+  A.a[6] -= 0.5 * w.y; A.a[7] += 0.5 * w.x;
+  const V3 p = M.p;
+  const double wTp = dot(w, p);
+  const V3 v3t = (bdot * wTp) * w - (t2 * bdot + 2.0 * beta) * p;
+  const double vv[3] = {v3t.x, v3t.y, v3t.z}, pv[3] = {p.x, p.y, p.z};
+  M3 Cm;
+  ASLR_UNROLL for (int i = 0; i < 3; ++i)
+    ASLR_UNROLL for (int j = 0; j < 3; ++j) Cm.a[3 * i + j] = vv[i] * wv[j] + beta * wv[i] * pv[j];
+  Cm.a[0] += wTp * beta; Cm.a[4] += wTp * beta; Cm.a[8] += wTp * beta;
+  Cm.a[1] -= 0.5 * p.z; Cm.a[2] += 0.5 * p.y;
+  Cm.a[3] += 0.5 * p.z; Cm.a[5] -= 0.5 * p.x;
+  Cm.a[6] -= 0.5 * p.y; Cm.a[7] += 0.5 * p.x;
+  Bm = mul(Cm, A);
+}
+
+// inverse of the SPD joint-space inertia via Cholesky with reciprocal pivots
+template <int N>
+ASLR_DEV void spd_inverse_fast(const double (&A)[N][N], double (&Ainv)[N][N]) {
+  double L[N][N], rinv[N];
+  ASLR_UNROLL for (int j = 0; j < N; ++j) {
+    double d = A[j][j];
+    ASLR_UNROLL for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    d = sqrt(d);
+    L[j][j] = d;
+    rinv[j] = 1.0 / d;
+    ASLR_UNROLL for (int i = j + 1; i < N; ++i) {
+      double s = A[i][j];
+      ASLR_UNROLL for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+      L[i][j] = s * rinv[j];
+    }
+  }
+  ASLR_UNROLL for (int j = 0; j < N; ++j) {
+    double e[N];
+    ASLR_UNROLL for (int i = 0; i < N; ++i) {
+      double s = (i == j) ? 1.0 : 0.0;
+      ASLR_UNROLL for (int k = 0; k < i; ++k) if (k >= j) s -= L[i][k] * e[k];
+      e[i] = (i < j) ? 0.0 : s * rinv[i];
+    }
+    ASLR_UNROLL for (int i = N - 1; i >= 0; --i) {
+      double s = e[i];
+      ASLR_UNROLL for (int k = i + 1; k < N; ++k) s -= L[k][i] * e[k];
+      e[i] = s * rinv[i];
+    }
+    ASLR_UNROLL for (int i = 0; i < N; ++i) Ainv[i][j] = e[i];
+  }
+}
+
+// what knot_eval computes
+constexpr int kEvalDyn = 1;  // xnext (dynamics + Euler step)
+constexpr int kEvalCost = 2; // cost
+constexpr int kEvalDiff = 4; // compact derivatives (implies both of the above)
+
+// calc (+ calcDiff): x[4NJ], u[NU] -> xnext, cost (+ compact derivatives).
 // u == nullptr selects the model's "u is None" default (terminal node).
-template <int NJ, int DAM, bool DIFF>
-ASLR_DEV void knot_eval(const aslr_chain_t &c, const DevModel &dm, const double *frame_ref,
+// CH is the chain policy (Chain3D / ChainPlanar); WHAT a mask of kEval* bits.
+template <int NJ, int DAM, int WHAT, class CH>
+ASLR_DEV void knot_eval(const DevDesc &D, const DevModel &dm, const double *frame_ref,
                         const double (&x)[4 * NJ], const double *u_in, double (&xnext)[4 * NJ],
                         double &cost_out, KnotDiff<NJ, ModelDims<NJ, DAM>::nu> *kd,
                         double *xout_o = nullptr) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
+  constexpr bool DIFF = (WHAT & kEvalDiff) != 0;
+  constexpr bool DYN = DIFF || (WHAT & kEvalDyn) != 0;
+  constexpr bool COST = DIFF || (WHAT & kEvalCost) != 0;
   const aslr_model_t &m = dm.m;
   double u[NU];
   if (u_in) {
@@ -416,88 +794,89 @@ ASLR_DEV void knot_eval(const aslr_chain_t &c, const DevModel &dm, const double 
   double q[NJ], v[NJ], dqm[NJ];
   ASLR_UNROLL for (int i = 0; i < NJ; ++i) { q[i] = x[i]; v[i] = x[2 * NJ + i]; dqm[i] = x[i] - x[NJ + i]; }
 
-  // stiffness / coupling torque / motor torque
-  double Kmat[NJ][NJ], tau_m[NJ], tau_c[NJ];
-  if (DAM == ASLR_DAM_VSA) {
-    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
-      ASLR_UNROLL for (int j = 0; j < NJ; ++j) Kmat[i][j] = (i == j) ? u[NJ + i] : 0.0;
-      tau_m[i] = u[i];
+  CH ch(D);
+  ch.setup(q);
+
+  if (DYN) {
+    // stiffness / coupling torque / motor torque
+    double Kmat[NJ][NJ], tau_m[NJ], tau_c[NJ];
+    if (DAM == ASLR_DAM_VSA) {
+      ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+        ASLR_UNROLL for (int j = 0; j < NJ; ++j) Kmat[i][j] = (i == j) ? u[NJ + i] : 0.0;
+        tau_m[i] = u[i];
+      }
+    } else {
+      ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+        double s = 0.0;
+        ASLR_UNROLL for (int j = 0; j < NJ; ++j) { Kmat[i][j] = m.K[i * NJ + j]; s += m.S[i * NU + j] * u[j]; }
+        tau_m[i] = s;
+      }
     }
-  } else {
     ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
       double s = 0.0;
-      ASLR_UNROLL for (int j = 0; j < NJ; ++j) { Kmat[i][j] = m.K[i * NJ + j]; s += m.S[i * NU + j] * u[j]; }
-      tau_m[i] = s;
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) s += Kmat[i][j] * dqm[j];
+      tau_c[i] = s;
     }
-  }
-  ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
-    double s = 0.0;
-    ASLR_UNROLL for (int j = 0; j < NJ; ++j) s += Kmat[i][j] * dqm[j];
-    tau_c[i] = s;
-  }
+    double M[NJ][NJ], Minv[NJ][NJ], nle[NJ];
+    ch.nle(v, nle);
+    ch.mass(M);
+    spd_inverse_fast<NJ>(M, Minv);
 
-  Kin<NJ> kin;
-  joint_placements<NJ>(c, q, kin);
-  const V3 grav = v3(c.gravity);
-  double M[NJ][NJ], Minv[NJ][NJ], nle[NJ], zero[NJ];
-  ASLR_UNROLL for (int i = 0; i < NJ; ++i) zero[i] = 0.0;
-  RneaWs<NJ> ws;
-  rnea<NJ, false>(c, kin, v, zero, grav, nle, ws);
-  crba<NJ>(c, kin, M);
-  spd_inverse<NJ>(M, Minv);
-
-  double xout[2 * NJ];
-  ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
-    double s = 0.0, s2 = 0.0;
-    ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
-      s += Minv[i][j] * (-nle[j] - tau_c[j]);
-      s2 += dm.Binv[i * NJ + j] * (tau_m[j] + tau_c[j]);
-    }
-    xout[i] = s;
-    xout[NJ + i] = s2;
-  }
-  if (xout_o) {
-    ASLR_UNROLL for (int i = 0; i < 2 * NJ; ++i) xout_o[i] = xout[i];
-  }
-  // semi-implicit Euler (integrated_action.py:23-24)
-  const double dt = m.dt;
-  ASLR_UNROLL for (int i = 0; i < 2 * NJ; ++i) {
-    xnext[i] = x[i] + (x[2 * NJ + i] * dt + xout[i] * dt * dt);
-    xnext[2 * NJ + i] = x[2 * NJ + i] + xout[i] * dt;
-  }
-
-  if (DIFF) {
-    double ddq[NJ][NJ], ddv[NJ][NJ];
-    rnea<NJ, true>(c, kin, v, xout, grav, zero /*discarded tau*/, ws);
-    rnea_derivatives<NJ>(c, kin, ws, ddq, ddv);
-    ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+    double xout[2 * NJ];
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+      double s = 0.0, s2 = 0.0;
       ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
-        double sq = 0.0, sk = 0.0, sv = 0.0, bk = 0.0;
-        ASLR_UNROLL for (int l = 0; l < NJ; ++l) {
-          sq += Minv[i][l] * (-ddq[l][j] - Kmat[l][j]);
-          sk += Minv[i][l] * Kmat[l][j];
-          sv += Minv[i][l] * (-ddv[l][j]);
-          bk += dm.Binv[i * NJ + l] * Kmat[l][j];
-        }
-        kd->Aqq[i][j] = sq; kd->Aqm[i][j] = sk; kd->Aqv[i][j] = sv; kd->Bk[i][j] = bk;
+        s += Minv[i][j] * (-nle[j] - tau_c[j]);
+        s2 += dm.Binv[i * NJ + j] * (tau_m[j] + tau_c[j]);
       }
-    ASLR_UNROLL for (int i = 0; i < NJ; ++i)
-      ASLR_UNROLL for (int j = 0; j < NU; ++j) { kd->Ful[i][j] = 0.0; kd->Fum[i][j] = 0.0; }
-    if (DAM == ASLR_DAM_VSA) {
+      xout[i] = s;
+      xout[NJ + i] = s2;
+    }
+    if (xout_o) {
+      ASLR_UNROLL for (int i = 0; i < 2 * NJ; ++i) xout_o[i] = xout[i];
+    }
+    // semi-implicit Euler (integrated_action.py:23-24)
+    const double dt = m.dt;
+    ASLR_UNROLL for (int i = 0; i < 2 * NJ; ++i) {
+      xnext[i] = x[i] + (x[2 * NJ + i] * dt + xout[i] * dt * dt);
+      xnext[2 * NJ + i] = x[2 * NJ + i] + xout[i] * dt;
+    }
+
+    if (DIFF) {
+      double ddq[NJ][NJ], ddv[NJ][NJ];
+      ch.rnea_derivatives(v, xout, ddq, ddv);
       ASLR_UNROLL for (int i = 0; i < NJ; ++i)
         ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
-          kd->Ful[i][NJ + j] = Minv[i][j] * (-x[j] + x[NJ + j]);
-          kd->Fum[i][NJ + j] = dm.Binv[i * NJ + j] * (x[j] - x[NJ + j]);
-          kd->Fum[i][j] = dm.Binv[i * NJ + j];
+          double sq = 0.0, sk = 0.0, sv = 0.0, bk = 0.0;
+          ASLR_UNROLL for (int l = 0; l < NJ; ++l) {
+            sq += Minv[i][l] * (-ddq[l][j] - Kmat[l][j]);
+            sk += Minv[i][l] * Kmat[l][j];
+            sv += Minv[i][l] * (-ddv[l][j]);
+            bk += dm.Binv[i * NJ + l] * Kmat[l][j];
+          }
+          kd->Aqq[i][j] = sq; kd->Aqm[i][j] = sk; kd->Aqv[i][j] = sv; kd->Bk[i][j] = bk;
         }
-    } else if (NU > 1) {
       ASLR_UNROLL for (int i = 0; i < NJ; ++i)
-        ASLR_UNROLL for (int j = 0; j < NU; ++j) {
-          double s = 0.0;
-          ASLR_UNROLL for (int l = 0; l < NJ; ++l) s += dm.Binv[i * NJ + l] * m.S[l * NU + j];
-          kd->Fum[i][j] = s;
-        }
+        ASLR_UNROLL for (int j = 0; j < NU; ++j) { kd->Ful[i][j] = 0.0; kd->Fum[i][j] = 0.0; }
+      if (DAM == ASLR_DAM_VSA) {
+        ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+          ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+            kd->Ful[i][NJ + j] = Minv[i][j] * (-x[j] + x[NJ + j]);
+            kd->Fum[i][NJ + j] = dm.Binv[i * NJ + j] * (x[j] - x[NJ + j]);
+            kd->Fum[i][j] = dm.Binv[i * NJ + j];
+          }
+      } else if (NU > 1) {
+        ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+          ASLR_UNROLL for (int j = 0; j < NU; ++j) {
+            double s = 0.0;
+            ASLR_UNROLL for (int l = 0; l < NJ; ++l) s += dm.Binv[i * NJ + l] * m.S[l * NU + j];
+            kd->Fum[i][j] = s;
+          }
+      }
     }
+  }
+  if (!COST) return;
+  if (DIFF) {
     ASLR_UNROLL for (int i = 0; i < NX; ++i) { kd->Lx[i] = 0.0; kd->Lxxd[i] = 0.0; }
     ASLR_UNROLL for (int i = 0; i < NU; ++i) { kd->Lu[i] = 0.0; kd->Luud[i] = 0.0; }
     ASLR_UNROLL for (int i = 0; i < NJ; ++i)
@@ -510,13 +889,8 @@ ASLR_DEV void knot_eval(const aslr_chain_t &c, const DevModel &dm, const double 
     const aslr_cost_t &ct = m.costs[ci];
     const double w = ct.weight;
     if (ct.type == ASLR_COST_FRAME_PLACEMENT) {
-      // oM(frame joint): the frame's joint index is runtime data; compose up to it
-      SE3d oMi[NJ];
-      oMi[0] = kin.liMi[0];
-      ASLR_UNROLL for (int i = 1; i < NJ; ++i) oMi[i] = se3_mul(oMi[i - 1], kin.liMi[i]);
       const int fj = ct.frame_joint;
-      SE3d oMj = oMi[0];
-      ASLR_UNROLL for (int i = 1; i < NJ; ++i) if (i == fj) oMj = oMi[i];
+      const SE3d oMj = ch.joint_world(fj);
       const SE3d F = SE3d{m3(ct.frame_R), v3(ct.frame_p)};
       const SE3d oMf = se3_mul(oMj, F);
       const double *ref = frame_ref ? frame_ref : ct.ref;
@@ -525,22 +899,18 @@ ASLR_DEV void knot_eval(const aslr_chain_t &c, const DevModel &dm, const double 
       SE3d rMf; // Mref^-1 * oMf
       rMf.R = mulTN(Rr, oMf.R);
       rMf.p = mulT(Rr, oMf.p - pr);
-      double r[6], theta;
-      V3 wlog;
-      log6(rMf, r, theta, wlog);
+      Log6 lg;
+      log6_shared(rMf, lg);
+      const double *r = lg.r;
       double a = 0.0;
       ASLR_UNROLL for (int i = 0; i < 6; ++i) a += ct.act_w[i] * r[i] * r[i];
       cost += w * 0.5 * a;
       if (DIFF) {
         M3 A, Bm;
-        jlog6(rMf, theta, wlog, A, Bm);
+        jlog6_shared(rMf, lg, A, Bm);
         double Jr[6][NJ];
         ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
-          // fJf column j = (oMf^-1 oMj).act(S_j); zero for joints past the frame's joint
-          SE3d fMj;
-          fMj.R = mulTN(oMf.R, oMi[j].R);
-          fMj.p = mulT(oMf.R, oMi[j].p - oMf.p);
-          SV col = motion_act(fMj, SV{V3{0, 0, 0}, v3(c.axis[j])});
+          SV col = ch.jac_col(j, oMf);
           if (j > fj) col = sv_zero();
           const V3 top = mul(A, col.lin) + mul(Bm, col.ang);
           const V3 bot = mul(A, col.ang);

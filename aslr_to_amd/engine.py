@@ -148,6 +148,13 @@ class Engine(object):
     def iterate(self, sp, first):
         _abi.check(self.lib.aslr_iterate(self.handle, C.byref(sp), 1 if first else 0, self._stream()), "aslr_iterate")
 
+    def iterate_timed(self, sp, first=False):
+        """-> (calc_ms, backward_ms, forward_ms) of one iteration, from HIP events on the launch stream."""
+        ms = (C.c_float * 3)()
+        _abi.check(self.lib.aslr_iterate_timed(self.handle, C.byref(sp), 1 if first else 0, self._stream(), ms),
+                   "aslr_iterate_timed")
+        return tuple(float(v) for v in ms)
+
     def finalize(self):
         _abi.check(self.lib.aslr_finalize(self.handle, self._stream()), "aslr_finalize")
 

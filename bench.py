@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched DDP hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json metric / configs[2], SURVEY.md 8(d) "C3"; C4 for N = 8): batched BoxDDP on the
+2-DoF VSA arm, T = 100, 4096 trajectories PER GPU (weak scaling; rank r owns rows
+[4096 r, 4096 (r+1)) of the seed-0 batch of 4096 N), synthetic seeded inputs, cold start,
+fixed-iteration mode (convergence exit disabled, as a throughput measurement needs).
+
+A "step" is ONE lock-step DDP iteration over the shard: calc/calcDiff sweep + backward pass (Riccati +
+BoxQP) + forward pass with the full 10-alpha line search.  W warm-up iterations are the first W
+iterations of the solve; the next K are timed between barrier + torch.cuda.synchronize() pairs; the
+maximum over ranks is taken.  value = knot-steps/s = (sum over ranks of B) * T * K / time.  Inputs are
+resident in HBM before the timed region.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel of the iteration: ALGORITHMIC bytes per launch (SURVEY.md 8(d)'s
+                per-knot-step figure for that phase x the B*T knot-steps one launch processes)
+                / its mean launch duration measured here with HIP events on the launch stream.
+  cpu_baseline  the CPU oracle (oracle/, a port -- Crocoddyl itself cannot be installed here) solving a
+                bounded sample of the same batch on the host cores, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T = 100
+B_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(nx, nu):
+    """bytes per knot-step of each phase (one accepted line-search trial)."""
+    n, m = nx, nu
+    blocks = 2 * n * n + 2 * n * m + m * m + n + m
+    p1 = 8 * ((n + m) + (n + 1) + blocks)          # calc + calcDiff: reads x,u; writes xnext,cost,blocks
+    p2 = 8 * (blocks + (m * n + 2 * m))            # backward: reads blocks; writes K,k,Qu
+    p3 = 8 * ((n + 2 * m + m * n) + (n + m + 1))   # forward, per trial
+    return p1, p2, p3
+
+
+def cpu_baseline(sc_fn, nthreads):
+    """Oracle (CPU port) solving the first trajectories of the same batch in converge mode."""
+    from aslr_to_amd import _abi, scenarios
+    from oracle import pyoracle
+    nsample = 16 * nthreads
+    sc = sc_fn(B=nsample, T=T, seed=0)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc)
+    t0 = time.perf_counter()
+    r = pyoracle.solve(low, sp, nthreads=nthreads)
+    dt = time.perf_counter() - t0
+    iters = int(r["traj_i"][_abi.TI_ITER].sum())
+    return {"value": iters * T / dt, "unit": "knot-steps/s", "cores": nthreads, "kind": "port",
+            "sample": "first %d trajectories of the seed-0 batch, full BoxDDP solves (th_stop 1e-7, maxiter 400), "
+                      "%d DDP iterations in %.2f s, OpenMP over trajectories" % (nsample, iters, dt),
+            "single_thread_note": "the reference forces nthreads = 1 (examples/double_pendulum.py:54)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=B_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from aslr_to_amd import _abi, dist, scenarios
+    from aslr_to_amd.crocoddyl import ShootingProblem
+
+    rank, world, local = dist.init_from_env()
+    if world != max(1, args.gpus) and world > 1:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local if world > 1 else 0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    Bg = args.batch_per_gpu
+    sc = scenarios.two_dof_vsa_boxddp(B=Bg * world, T=T, seed=0)
+    problem = ShootingProblem(sc["x0"], sc["running"], sc["terminal"], frame_refs=sc["frame_refs"],
+                              rank=rank, world_size=world, device=dev)
+    e = problem.engine
+    sp = scenarios.solver_params(sc, fixed_iterations=1, maxiter=args.warmup + args.steps)
+    e.set_candidate(None, None)  # cold start, as examples/two_dof_vsa_boxddp.py:81
+
+    for i in range(args.warmup):
+        e.iterate(sp, i == 0)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        e.iterate(sp, args.warmup == 0 and i == 0)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
+
+    # per-kernel durations (HIP events on the launch stream), a few more iterations of the same solve
+    nprobe = 10
+    acc = [0.0, 0.0, 0.0]
+    for _ in range(nprobe):
+        ms = e.iterate_timed(sp)
+        acc = [a + m for a, m in zip(acc, ms)]
+    k_ms = [a / nprobe for a in acc]
+    e.finalize()
+    torch.cuda.synchronize(dev)
+    stats = dist.all_reduce_stats(dist.local_stats(e))  # the ONE collective of a solve (RCCL over xGMI)
+
+    if rank != 0:
+        return
+    knot_steps = Bg * world * T * args.steps
+    value = knot_steps / elapsed
+    p1, p2, p3 = algorithmic_bytes(e.nx, e.nu)
+    names = ["calc_kernel", "backward_kernel", "forward_kernel"]
+    # the sequential line search of the algorithm needs (accepted index + 1) trials; the kernel evaluates
+    # all 10 step lengths at once, but only the required ones count as algorithmic traffic
+    trials = stats["trials_sum"] / max(stats["iters_sum"], 1)
+    phase_bytes = [p1, p2, p3 * trials]
+    dom = max(range(3), key=lambda i: k_ms[i])
+    launch_bytes = phase_bytes[dom] * Bg * T
+    achieved = launch_bytes / (k_ms[dom] * 1e-3) / 1e9
+    out = {
+        "metric": "knot-steps/s (batched BoxDDP, 2-DoF VSA, T=100, 4096 trajectories per GPU)",
+        "value": value, "unit": "knot-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "two_dof_vsa_boxddp (examples/two_dof_vsa_boxddp.py, T=100): SolverBoxDDP, "
+                               "cold start, fixed-iteration mode, full 10-alpha line search every iteration",
+                   "batch_per_gpu": Bg, "global_batch": Bg * world, "T": T, "nx": e.nx, "nu": e.nu,
+                   "sharding": "contiguous batch blocks, no data-path collective"},
+        "ddp_iterations_per_s": args.steps / elapsed,
+        "trajectory_iterations_per_s": Bg * world * args.steps / elapsed,
+        "line_search_trials_per_iteration": trials,
+        "kernel_ms": dict(zip(names, k_ms)),
+        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_knot_step": phase_bytes[dom],
+                     "knot_steps_per_launch": Bg * T},
+        "roofline_iteration": {"algorithmic_bytes_per_knot_step": p1 + p2 + p3,
+                               "achieved": (p1 + p2 + p3) * value / world / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s per GPU", "frac": (p1 + p2 + p3) * value / world / 1e9 / HBM_PEAK_GBS,
+                               "note": "SURVEY.md 8(d) whole-iteration figure (4496 B per knot-step at nx=8, nu=4)"},
+        "solver_state": stats,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            nthreads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            nthreads = os.cpu_count() or 1
+        nthreads = min(nthreads, 16)  # the CPU share of a one-GPU box
+        out["cpu_baseline"] = cpu_baseline(scenarios.two_dof_vsa_boxddp, nthreads)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

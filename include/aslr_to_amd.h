@@ -156,8 +156,8 @@ typedef struct aslr_solver_params {
   int32_t boxqp_maxiter;             /* 100   */
   int32_t _pad0;
   double boxqp_th_acceptstep;        /* 0.1   */
-  double boxqp_th_grad;              /* 1e-9  */
-  double boxqp_reg;                  /* 1e-9  */
+  double boxqp_th_grad;              /* 1e-5: SolverBoxDDP builds its BoxQP as (nu, 100, 0.1, 1e-5, 0.) */
+  double boxqp_reg;                  /* 0     */
 } aslr_solver_params_t;
 
 /* Named regions of the device workspace.  Layouts (doubles unless noted), time-major so that a
@@ -257,6 +257,11 @@ int aslr_solve(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t poll_e
 /* one lock-step DDP iteration (calcDiff sweep + backward pass + line search), the unit the
  * benchmark's "step" times.  `first` != 0 re-initialises the per-trajectory solver state. */
 int aslr_iterate(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream);
+/* aslr_iterate with HIP events recorded on `stream` around each of its three kernels
+ * (calc/calcDiff sweep, backward pass, forward pass + line search); waits for the last event and
+ * returns the three durations in milliseconds.  Measurement aid for bench.py's roofline leg. */
+int aslr_iterate_timed(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream,
+                       float *ms3);
 /* commit the last accepted line-search candidate into XS/US (called by aslr_solve on exit). */
 int aslr_finalize(aslr_problem_t *p, void *stream);
 /* number of trajectories neither converged nor failed; synchronises `stream`. */

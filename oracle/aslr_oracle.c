@@ -822,6 +822,13 @@ int aslr_cpu_calc(const aslr_problem_desc_t *d, const double *xs, const double *
 /* ======================================================================================= */
 /* BoxQP (Tassa et al. 2014 projected Newton)                                */
 /* ======================================================================================= */
+/* diagnostics (serial runs only): number of calls, projected-Newton iterations, line-search trials */
+static long long g_qp_calls, g_qp_iters, g_qp_trials, g_qp_maxed;
+void aslr_cpu_boxqp_stats(long long *out4, int reset) {
+  out4[0] = g_qp_calls; out4[1] = g_qp_iters; out4[2] = g_qp_trials; out4[3] = g_qp_maxed;
+  if (reset) g_qp_calls = g_qp_iters = g_qp_trials = g_qp_maxed = 0;
+}
+
 int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, const double *ub,
                    double *x, int maxiter, double th_acceptstep, double th_grad, double reg,
                    double *Hff_inv, int32_t *free_idx, int32_t *nf_o, int32_t *clamped_idx,
@@ -829,7 +836,9 @@ int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, co
   double g[NU], dx[NU], xnew[NU], Hff[NU * NU], L[NU * NU];
   int nf = 0, nc = 0, k;
   for (int i = 0; i < n; ++i) x[i] = fmax(fmin(x[i], ub[i]), lb[i]);
+  g_qp_calls++;
   for (k = 0; k < maxiter; ++k) {
+    g_qp_iters++;
     nf = nc = 0;
     for (int i = 0; i < n; ++i) {
       double s = q[i];
@@ -879,6 +888,7 @@ int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, co
     }
     double alpha = 1.0;
     for (int a = 0; a < ASLR_NALPHA; ++a, alpha *= 0.5) {
+      g_qp_trials++;
       for (int i = 0; i < n; ++i) xnew[i] = fmax(fmin(x[i] + alpha * dx[i], ub[i]), lb[i]);
       double fnew = 0.0, gd = 0.0;
       for (int i = 0; i < n; ++i) {
@@ -894,6 +904,7 @@ int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, co
     }
   }
   *nf_o = nf; *nc_o = nc;
+  g_qp_maxed++;
   return k;
 }
 

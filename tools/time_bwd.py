@@ -1,0 +1,25 @@
+import sys, numpy as np, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aslr_to_amd import scenarios, _abi as A
+from aslr_to_amd.engine import Engine
+B = 4096
+sc = scenarios.two_dof_vsa_boxddp(B=B, T=100)
+low = scenarios.lower(sc)
+e = Engine(low)
+e.set_candidate(None, None)
+def ev(): return torch.cuda.Event(enable_timing=True)
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize(); a, b = ev(), ev(); a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / n * 1e3
+sp_box = scenarios.solver_params(sc, fixed_iterations=1)
+sp_ddp = scenarios.solver_params(sc, solver="SolverDDP", fixed_iterations=1)
+for i in range(3): e.iterate(sp_box, i == 0)
+torch.cuda.synchronize()
+for feas in (0, 1):
+    e.region(A.R_TRAJ_I)[A.TI_FEASIBLE].fill_(feas)
+    print("feasible=%d  backward DDP: %.1f us   Box: %.1f us" % (feas, timeit(lambda: e.backward_pass(sp_ddp)), timeit(lambda: e.backward_pass(sp_box))))
+for n in (10, 30, 60):
+    for i in range(n): e.iterate(sp_box, False)
+    e.region(A.R_TRAJ_I)[A.TI_FEASIBLE].fill_(1)
+    print("after +%d its: backward Box: %.1f us, DDP %.1f us" % (n, timeit(lambda: e.backward_pass(sp_box)), timeit(lambda: e.backward_pass(sp_ddp))))
