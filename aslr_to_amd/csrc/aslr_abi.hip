@@ -102,6 +102,7 @@ void carve(const aslr_problem_desc_t *d, int nx, int nu, aslr_region_t *r, int64
   sizes[ASLR_R_VXXF] = T1 * B * nx * D;
   sizes[ASLR_R_DESC] = sizeof(DevDesc);
   sizes[ASLR_R_NODE_MODEL] = T1 * sizeof(int32_t);
+  sizes[ASLR_R_COST_TRY] = (int64_t)ASLR_NALPHA * T1 * B * D;
   int64_t off = 0;
   for (int i = 0; i < ASLR_R_COUNT; ++i) {
     r[i].offset = off;
@@ -184,6 +185,16 @@ int launch_calc(aslr_problem *p, bool diff, int mode, double th_gaptol, hipStrea
   return ASLR_E_INVALID;
 }
 
+ModelLimits make_limits(const aslr_problem *p) {
+  ModelLimits lim;
+  memset(&lim, 0, sizeof lim);
+  for (int i = 0; i < p->desc.nmodels; ++i) {
+    lim.has[i] = p->desc.models[i].has_u_limits;
+    for (int c = 0; c < ASLR_MAX_NU; ++c) { lim.lb[i][c] = p->desc.models[i].u_lb[c]; lim.ub[i][c] = p->desc.models[i].u_ub[c]; }
+  }
+  return lim;
+}
+
 int backward_hs(const aslr_problem *p) {
   // rows of each column split over HS lanes: wider teams when the batch cannot fill the chip
   const char *e = getenv("ASLR_BWD_HS");
@@ -193,12 +204,7 @@ int backward_hs(const aslr_problem *p) {
 
 int launch_backward(aslr_problem *p, const SolverDev &sd, hipStream_t st) {
   const int hs = backward_hs(p);
-  ModelLimits lim;
-  memset(&lim, 0, sizeof lim);
-  for (int i = 0; i < p->desc.nmodels; ++i) {
-    lim.has[i] = p->desc.models[i].has_u_limits;
-    for (int c = 0; c < ASLR_MAX_NU; ++c) { lim.lb[i][c] = p->desc.models[i].u_lb[c]; lim.ub[i][c] = p->desc.models[i].u_ub[c]; }
-  }
+  const ModelLimits lim = make_limits(p);
   if (p->nx == 8) return launch_backward_nx8(p->k, p->nu, hs, sd, lim, st);
   if (p->nx == 28) return launch_backward_nx28(p->k, p->nu, hs, sd, lim, st);
   snprintf(g_err, sizeof g_err, "unsupported (nx=%d, nu=%d)", p->nx, p->nu);
@@ -206,8 +212,9 @@ int launch_backward(aslr_problem *p, const SolverDev &sd, hipStream_t st) {
 }
 
 int launch_forward(aslr_problem *p, const SolverDev &sd, hipStream_t st) {
-  if (p->nj == 2) return launch_forward_nj2(p->k, p->dam, sd, st);
-  if (p->nj == 7) return launch_forward_nj7(p->k, p->dam, sd, st);
+  const ModelLimits lim = make_limits(p);
+  if (p->nj == 2) return launch_forward_nj2(p->k, p->dam, sd, lim, st);
+  if (p->nj == 7) return launch_forward_nj7(p->k, p->dam, sd, lim, st);
   snprintf(g_err, sizeof g_err, "unsupported nj=%d", p->nj);
   return ASLR_E_INVALID;
 }
@@ -335,6 +342,7 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   k.kgain = (double *)reg(ASLR_R_KGAIN); k.kff = (double *)reg(ASLR_R_KFF); k.qu = (double *)reg(ASLR_R_QU);
   k.vx = (double *)reg(ASLR_R_VX); k.vxx = (double *)reg(ASLR_R_VXX); k.xs_try = (double *)reg(ASLR_R_XS_TRY);
   k.us_try = (double *)reg(ASLR_R_US_TRY); k.vxxf = (double *)reg(ASLR_R_VXXF);
+  k.cost_try = (double *)reg(ASLR_R_COST_TRY);
   k.traj_f = (double *)reg(ASLR_R_TRAJ_F); k.traj_i = (int32_t *)reg(ASLR_R_TRAJ_I);
   k.B = desc->B; k.T = desc->T;
   k.planar = planar_ok;

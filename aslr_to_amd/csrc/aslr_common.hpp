@@ -32,7 +32,7 @@ struct KArgs {
   const int32_t *node_model;
   const double *x0;
   const double *frame_ref; // nullable
-  double *xs, *us, *xnext, *cost, *deriv, *gaps, *kgain, *kff, *qu, *vx, *vxx, *xs_try, *us_try, *vxxf;
+  double *xs, *us, *xnext, *cost, *deriv, *gaps, *kgain, *kff, *qu, *vx, *vxx, *xs_try, *us_try, *vxxf, *cost_try;
   double *traj_f;
   int32_t *traj_i;
   int32_t B, T;
@@ -76,7 +76,7 @@ int launch_dam_eval_nj7(const KArgs &k, int dam, int mi, int n, const double *x,
                         double *Luu, hipStream_t st);
 int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, hipStream_t st);
 int launch_backward_nx28(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, hipStream_t st);
-int launch_forward_nj2(const KArgs &k, int dam, const SolverDev &sd, hipStream_t st);
-int launch_forward_nj7(const KArgs &k, int dam, const SolverDev &sd, hipStream_t st);
+int launch_forward_nj2(const KArgs &k, int dam, const SolverDev &sd, const ModelLimits &lim, hipStream_t st);
+int launch_forward_nj7(const KArgs &k, int dam, const SolverDev &sd, const ModelLimits &lim, hipStream_t st);
 
 } // namespace aslr

@@ -1,11 +1,17 @@
-// forward pass instantiated for nj = 7
+// forward pass (rollout + trial costs + line search) instantiated for nj = 7
 #include "aslr_forward.inc.hpp"
 
 namespace aslr {
-int launch_forward_nj7(const KArgs &k, int dam, const SolverDev &sd, hipStream_t st) {
-  dim3 grid((k.B + 3) / 4), block(64);
+int launch_forward_nj7(const KArgs &k, int dam, const SolverDev &sd, const ModelLimits &lim, hipStream_t st) {
+  dim3 grid((k.B + 3) / 4), block(64), cgrid((k.B + 255) / 256, k.T + 1, ASLR_NALPHA), sgrid((k.B + 63) / 64),
+      cblock(256), ugrid((k.B + 63) / 64, ASLR_NALPHA);
   if (dam == ASLR_DAM_SEA) {
-    hipLaunchKernelGGL((forward_kernel<7, ASLR_DAM_SEA, false>), grid, block, 0, st, k, sd);
+    {
+      hipLaunchKernelGGL((rollout_kernel<7, ASLR_DAM_SEA, false>), grid, block, 0, st, k, sd, lim);
+      hipLaunchKernelGGL((trial_cost_kernel<7, ASLR_DAM_SEA, false>), cgrid, cblock, 0, st, k, sd);
+    }
+    hipLaunchKernelGGL((sum_cost_kernel<7>), ugrid, block, 0, st, k, sd);
+    hipLaunchKernelGGL((select_kernel<7>), sgrid, block, 0, st, k, sd);
     HIP_TRY(hipGetLastError());
     return ASLR_OK;
   }

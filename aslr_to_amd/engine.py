@@ -74,7 +74,7 @@ class Engine(object):
             _abi.R_VX: (T + 1, B, nx), _abi.R_VXX: (T + 1, B, nx, nx),
             _abi.R_XS_TRY: (_abi.NALPHA, T + 1, B, nx), _abi.R_US_TRY: (_abi.NALPHA, T, B, nu),
             _abi.R_TRAJ_F: (_abi.TF_COUNT, B), _abi.R_X0: (B, nx), _abi.R_FRAME_REF: (B, 12),
-            _abi.R_VXXF: (T + 1, B, nx),
+            _abi.R_VXXF: (T + 1, B, nx), _abi.R_COST_TRY: (_abi.NALPHA, T + 1, B),
         }
         if rid == _abi.R_TRAJ_I:
             v = raw.view(torch.int32).view(_abi.TI_COUNT, B)

@@ -177,6 +177,7 @@ typedef struct aslr_solver_params {
  *   XS_TRY  [NALPHA][T+1][B][nx]  line-search candidates
  *   US_TRY  [NALPHA][T][B][nu]
  *   VXXF    [T+1][B][nx]        Vxx[t] fs[t] (FDDP expected improvement)
+ *   COST_TRY [NALPHA][T+1][B]   node costs of every line-search candidate
  *   TRAJ_F  [ASLR_TF_COUNT][B]  per-trajectory doubles (ASLR_TF_*)
  *   TRAJ_I  [ASLR_TI_COUNT][B]  per-trajectory int32   (ASLR_TI_*)
  */
@@ -184,7 +185,7 @@ enum aslr_region_id {
   ASLR_R_XS = 0, ASLR_R_US, ASLR_R_XNEXT, ASLR_R_COST, ASLR_R_DERIV, ASLR_R_GAPS,
   ASLR_R_KGAIN, ASLR_R_KFF, ASLR_R_QU, ASLR_R_VX, ASLR_R_VXX, ASLR_R_XS_TRY, ASLR_R_US_TRY,
   ASLR_R_TRAJ_F, ASLR_R_TRAJ_I, ASLR_R_X0, ASLR_R_FRAME_REF, ASLR_R_VXXF, ASLR_R_DESC,
-  ASLR_R_NODE_MODEL, ASLR_R_COUNT
+  ASLR_R_NODE_MODEL, ASLR_R_COST_TRY, ASLR_R_COUNT
 };
 
 /* rows of TRAJ_F */
@@ -199,7 +200,8 @@ enum {
   ASLR_TI_ITER = 0, ASLR_TI_STATUS, ASLR_TI_FEASIBLE, ASLR_TI_WAS_FEASIBLE, ASLR_TI_RECALC,
   ASLR_TI_ACCEPTED /* index of accepted alpha, -1 none */, ASLR_TI_DONE, ASLR_TI_NTRIALS,
   ASLR_TI_GAPFLAG /* some |gap| >= th_gaptol seen by the last calcDiff sweep */,
-  ASLR_TI_COUNT
+  ASLR_TI_TRYFAIL0 /* ..+NALPHA: the rollout of that step length produced NaN / Inf ("forward_error") */,
+  ASLR_TI_COUNT = ASLR_TI_TRYFAIL0 + ASLR_NALPHA
 };
 
 typedef struct aslr_region {
@@ -245,7 +247,8 @@ int aslr_calc_diff(aslr_problem_t *p, void *stream);
  * writes KGAIN, KFF, QU, VX, VXX, TRAJ_F[D1,D2,STOP,DG,DQ], TRAJ_I[STATUS]. */
 int aslr_backward_pass(aslr_problem_t *p, const aslr_solver_params_t *sp, void *stream);
 /* SolverDDP/FDDP/BoxDDP.forwardPass for all ASLR_NALPHA step lengths.
- * Reads XS, US, KGAIN, KFF, GAPS; writes XS_TRY, US_TRY, TRAJ_F[COST_TRY0..]. */
+ * Reads XS, US, KGAIN, KFF, GAPS; writes XS_TRY, US_TRY, COST_TRY, TRAJ_F[COST_TRY0..] (NaN for a
+ * step length whose rollout failed). */
 int aslr_forward_pass(aslr_problem_t *p, const aslr_solver_params_t *sp, void *stream);
 /* solver.solve(init_xs, init_us, maxiter, isFeasible, regInit) (examples/two_dof_vsa_boxddp.py:81):
  * XS/US hold the warm start on entry and the solution on exit; TRAJ_F/TRAJ_I the per-trajectory

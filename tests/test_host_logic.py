@@ -57,6 +57,7 @@ def test_workspace_size_is_the_sum_of_the_documented_regions():
     B, T, nx, nu, rec = 70, 9, 8, 4, 224
     doubles = ((T + 1) * B * nx * 5 + T * B * nu * 3 + (T + 1) * B + (T + 1) * B * rec + T * B * nu * nx
                + (T + 1) * B * nx * nx + 10 * (T + 1) * B * nx + 10 * T * B * nu + _abi.TF_COUNT * B + B * nx + B * 12)
+    doubles += 10 * (T + 1) * B  # COST_TRY
     assert doubles * 8 <= n <= doubles * 8 + 64 * 1024
     bad = scenarios.lower(sc)
     bad.desc.B = 0
