@@ -36,104 +36,116 @@ ASLR_DEV bool chol_rs(double (&A)[N][N], double (&rinv)[N]) {
   return bad;
 }
 
-// BoxQP on register arrays, evaluated redundantly by every lane of a team.  The free
-// subspace is handled by masking: clamped rows/columns of H become identity rows, which makes the
-// Cholesky of the masked matrix reproduce the factor of Hff exactly (the extra operands are 0 / 1).
-// On exit: x, the clamped mask of the final active set, and in `kcol` the column Quu_inv * kcol_in
-// where Quu_inv is zero outside the free block and Hff^-1 inside (Crocoddyl forms Hff^-1 explicitly
-// and multiplies; solving with the same factor differs by rounding only).  The factor of the last
-// Newton step is reused when the final active set is the one it was built for.
+// BoxQP on register arrays, evaluated redundantly by every lane of a team.
+//
+// Branch-free formulation: the free / clamped split is carried by multiplicative masks mk[i] in {1, 0}
+// (free / clamped).  The masked matrix  mk_i mk_j H_ij + (1 - mk_i) delta_ij  has the Cholesky factor
+// of Hff in its free block and identity rows elsewhere; multiplying by exact 0 / 1 and adding exact
+// zeros changes no bits, so every quantity equals what the index-set formulation computes.  All teams of
+// a wave step together (wave-uniform loop control by ballot); a team that has converged keeps its
+// state through selects and its factor is simply rebuilt from its (final) mask.
+// On exit: x, the clamped flags of the final active set, and kcol <- Quu_inv kcol where Quu_inv is
+// Hff^-1 on the free block and zero elsewhere (Crocoddyl forms Hff^-1 explicitly and multiplies; solving
+// with the same factor differs by rounding only).
 template <int NU>
 ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const double (&lb)[NU],
                     const double (&ub)[NU], double (&x)[NU], bool (&cm)[NU], double (&kcol)[NU],
                     int boxqp_maxiter, double th_acceptstep, double th_grad, double reg) {
-  bool bad = false, finished = false, have_factor = false;
-  bool cmL[NU];
-  double L[NU][NU], rinv[NU];
-  ASLR_UNROLL for (int i = 0; i < NU; ++i) { x[i] = fmax(fmin(x[i], ub[i]), lb[i]); cm[i] = false; cmL[i] = false; }
-  int nf = NU;
-  for (int it = 0; it < boxqp_maxiter; ++it) {
-    if (!finished) {
-      double g[NU];
-      ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-        double s = q[i];
-        ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
-        g[i] = s;
-      }
-      double gnorm = 0.0;
-      nf = 0;
-      ASLR_UNROLL for (int j = 0; j < NU; ++j) {
-        cm[j] = (x[j] == lb[j] && g[j] > 0.0) || (x[j] == ub[j] && g[j] < 0.0);
-        if (!cm[j]) { gnorm = fmax(gnorm, fabs(g[j])); ++nf; }
-      }
-      if (gnorm <= th_grad || nf == 0) {
-        finished = true;
-      } else {
-        ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-          cmL[i] = cm[i];
-          ASLR_UNROLL for (int j = 0; j < NU; ++j)
-            L[i][j] = (cm[i] || cm[j]) ? (i == j ? 1.0 : 0.0) : (H[i][j] + (i == j ? reg : 0.0));
-        }
-        have_factor = true;
-        if (chol_rs<NU>(L, rinv)) { bad = true; finished = true; }
-        // dx_f = -Hff^-1 (q_f + H_fc x_c) - x_f
-        double rhs[NU], dx[NU];
-        ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-          double s = -q[i];
-          ASLR_UNROLL for (int j = 0; j < NU; ++j) if (cm[j]) s -= H[i][j] * x[j];
-          rhs[i] = cm[i] ? 0.0 : s;
-        }
-        chol_solve_r<NU>(L, rinv, rhs);
-        double fold = 0.0;
-        ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-          dx[i] = cm[i] ? 0.0 : rhs[i] - x[i];
-          double s = 0.0;
-          ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
-          fold += 0.5 * x[i] * s + q[i] * x[i];
-        }
-        double alpha = 1.0;
-        bool found = false;
-        for (int al = 0; al < ASLR_NALPHA; ++al, alpha *= 0.5) {
-          if (!found) {
-            double xn[NU], fnew = 0.0, gd = 0.0;
-            ASLR_UNROLL for (int i = 0; i < NU; ++i) xn[i] = fmax(fmin(x[i] + alpha * dx[i], ub[i]), lb[i]);
-            ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-              double s = 0.0;
-              ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * xn[j];
-              fnew += 0.5 * xn[i] * s + q[i] * xn[i];
-              gd += g[i] * (x[i] - xn[i]);
-            }
-            if (fold - fnew > th_acceptstep * gd) {
-              ASLR_UNROLL for (int i = 0; i < NU; ++i) x[i] = xn[i];
-              found = true;
-            }
-          }
-          if (__ballot(!found) == 0ull) break;
-        }
-      }
-    }
-    if (__ballot(!finished) == 0ull) break;
+  bool bad = false, finished = false;
+  double mk[NU], mkL[NU], L[NU][NU], rinv[NU];
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+    x[i] = fmax(fmin(x[i], ub[i]), lb[i]);
+    mk[i] = 1.0; mkL[i] = -1.0; cm[i] = false; rinv[i] = 1.0;
+    ASLR_UNROLL for (int j = 0; j < NU; ++j) L[i][j] = 0.0;
   }
-  // factor of the final free block (kept from the last Newton step when the active set is unchanged)
-  bool same = have_factor;
-  ASLR_UNROLL for (int i = 0; i < NU; ++i) same = same && (cmL[i] == cm[i]);
-  if (!same) {
-    ASLR_UNROLL for (int i = 0; i < NU; ++i)
+  auto factor = [&]() {
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+      mkL[i] = mk[i];
       ASLR_UNROLL for (int j = 0; j < NU; ++j)
-        L[i][j] = (cm[i] || cm[j]) ? (i == j ? 1.0 : 0.0) : (H[i][j] + (i == j ? reg : 0.0));
-    if (chol_rs<NU>(L, rinv) && nf > 0) bad = true;
+        L[i][j] = (mk[i] * mk[j]) * H[i][j] + (i == j ? (mk[i] * reg + (1.0 - mk[i])) : 0.0);
+    }
+    return chol_rs<NU>(L, rinv);
+  };
+  for (int it = 0; it < boxqp_maxiter; ++it) {
+    double g[NU], Hx[NU];
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+      double s = 0.0;
+      ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
+      Hx[i] = s;
+      g[i] = q[i];
+    }
+    // g = q + H x accumulated in the oracle's order (q first)
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+      double s = q[i];
+      ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
+      g[i] = s;
+    }
+    double gnorm = 0.0, nfree = 0.0;
+    bool cmn[NU];
+    ASLR_UNROLL for (int j = 0; j < NU; ++j) {
+      cmn[j] = (x[j] == lb[j] && g[j] > 0.0) || (x[j] == ub[j] && g[j] < 0.0);
+      const double mj = cmn[j] ? 0.0 : 1.0;
+      gnorm = fmax(gnorm, mj * fabs(g[j]));
+      nfree += mj;
+      if (!finished) { cm[j] = cmn[j]; mk[j] = mj; }
+    }
+    const bool fin_now = finished || (gnorm <= th_grad) || (nfree == 0.0);
+    if (__ballot(!fin_now) == 0ull) { finished = true; break; }
+    // Newton step on the free subspace (teams already finished just rebuild their own factor)
+    const bool cbad = factor();
+    if (cbad && !fin_now) bad = true;
+    const bool stepping = !fin_now && !cbad;
+    double rhs[NU], dx[NU];
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+      double s = -q[i];
+      ASLR_UNROLL for (int j = 0; j < NU; ++j) s -= H[i][j] * ((1.0 - mk[j]) * x[j]);
+      rhs[i] = mk[i] * s;
+    }
+    chol_solve_r<NU>(L, rinv, rhs);
+    double fold = 0.0;
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+      dx[i] = mk[i] * (rhs[i] - x[i]);
+      fold += 0.5 * x[i] * Hx[i] + q[i] * x[i];
+    }
+    double alpha = 1.0;
+    bool found = !stepping;
+    for (int al = 0; al < ASLR_NALPHA; ++al, alpha *= 0.5) {
+      double xn[NU], fnew = 0.0, gd = 0.0;
+      ASLR_UNROLL for (int i = 0; i < NU; ++i) xn[i] = fmax(fmin(x[i] + alpha * dx[i], ub[i]), lb[i]);
+      ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+        double s = 0.0;
+        ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * xn[j];
+        fnew += 0.5 * xn[i] * s + q[i] * xn[i];
+        gd += g[i] * (x[i] - xn[i]);
+      }
+      const bool take = !found && (fold - fnew > th_acceptstep * gd);
+      ASLR_UNROLL for (int i = 0; i < NU; ++i) x[i] = take ? xn[i] : x[i];
+      found = found || take;
+      if (__ballot(!found) == 0ull) break;
+    }
+    finished = fin_now || cbad;
   }
-  ASLR_UNROLL for (int i = 0; i < NU; ++i) if (cm[i]) kcol[i] = 0.0;
+  // factor of the final free block: the one at hand unless the active set changed in the last step
+  bool stale = false;
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) stale = stale || (mkL[i] != mk[i]);
+  if (__ballot(stale) != 0ull) {
+    double nfree = 0.0;
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) nfree += mk[i];
+    if (factor() && nfree > 0.0) bad = true;
+  }
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) kcol[i] *= mk[i];
   chol_solve_r<NU>(L, rinv, kcol);
-  ASLR_UNROLL for (int i = 0; i < NU; ++i) if (cm[i]) kcol[i] = 0.0;
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) kcol[i] *= mk[i];
   return bad;
 }
 
-template <int NX, int NU, int HS>
+// TPWA: teams actually used per wave (<= 64 / TEAM).  Fewer teams per wave means more waves (idle issue
+// slots are plentiful at 4096 trajectories per GPU) and less lock-step waste in the per-team BoxQP loops.
+template <int NX, int NU, int HS, int TPWA = 0>
 struct BwdCfg {
   static constexpr int NXP = NX <= 8 ? 8 : 32;
   static constexpr int TEAM = NXP * HS;
-  static constexpr int TPW = 64 / TEAM;
+  static constexpr int TPW = (TPWA > 0 && TPWA < 64 / TEAM) ? TPWA : 64 / TEAM;
   static constexpr int RPL = (NX + HS - 1) / HS;
   static constexpr bool EXACT = (RPL * HS == NX); // rows divide evenly: no clamping of row indices
   static constexpr int REC = rec_len_c(NX, NU);
@@ -147,23 +159,23 @@ struct BwdCfg {
   static constexpr int NPRE = (REC / 2 + TEAM - 1) / TEAM; // double2 prefetch registers per lane
 };
 
-template <int NX, int NU, int HS>
+template <int NX, int NU, int HS, int TPWA>
 __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
-  using C = BwdCfg<NX, NU, HS>;
+  using C = BwdCfg<NX, NU, HS, TPWA>;
   constexpr int NXP = C::NXP, TEAM = C::TEAM, TPW = C::TPW, RPL = C::RPL, REC = C::REC;
   extern __shared__ double smem[];
 
   const int lane = threadIdx.x, team = lane / TEAM, lt = lane % TEAM, j = lt % NXP, h = lt / NXP;
   const int B = a.B, T = a.T;
   const int bq = blockIdx.x * TPW + team;
-  const bool team_valid = bq < B;
+  const bool team_valid = team < TPW && bq < B;
   const int b = team_valid ? bq : B - 1;
   const bool col_valid = j < NX;
   const int jj = col_valid ? j : NX - 1;
   const bool writer = team_valid && col_valid && h == 0;
   const int r0 = h * RPL;
   const int ju = jj < NU ? jj : NU - 1;
-  double *sm = smem + team * C::LDS_TEAM;
+  double *sm = smem + (team < TPW ? team : 0) * C::LDS_TEAM;
   double *rec = sm + C::sRec, *AT = sm + C::sAT, *BT = sm + C::sBT, *QuxL = sm + C::sQux, *VT = sm + C::sVT,
          *QuuL = sm + C::sQuu, *QuL = sm + C::sQu, *VxL = sm + C::sVx;
   auto row = [&](int i) { return C::EXACT ? r0 + i : (r0 + i < NX ? r0 + i : NX - 1); };
@@ -491,12 +503,12 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
   }
 }
 
-template <int NX, int NU, int HS>
+template <int NX, int NU, int HS, int TPWA = 0>
 int launch_backward_t(const KArgs &k, const SolverDev &sd, const ModelLimits &lim, hipStream_t st) {
-  using C = BwdCfg<NX, NU, HS>;
+  using C = BwdCfg<NX, NU, HS, TPWA>;
   const int blocks = (k.B + C::TPW - 1) / C::TPW;
   const size_t lds = (size_t)C::TPW * C::LDS_TEAM * sizeof(double);
-  hipLaunchKernelGGL((backward_kernel<NX, NU, HS>), dim3(blocks), dim3(64), lds, st, k, sd, lim);
+  hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA>), dim3(blocks), dim3(64), lds, st, k, sd, lim);
   HIP_TRY(hipGetLastError());
   return ASLR_OK;
 }

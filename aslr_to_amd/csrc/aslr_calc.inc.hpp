@@ -72,7 +72,10 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
   KnotDiff<NJ, NU> kd;
   if (compute) {
     using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
-    knot_eval<NJ, DAM, DIFF ? kEvalDiff : (kEvalDyn | kEvalCost), CH>(D, dm, fref, x, t < T ? u : nullptr, xnext, cost, DIFF ? &kd : nullptr);
+    const typename CH::Consts cc(D);
+    ModelRegs<NJ, NU> mr;
+    mr.load(dm);
+    knot_eval<NJ, DAM, DIFF ? kEvalDiff : (kEvalDyn | kEvalCost), CH>(cc, mr, dm, fref, x, t < T ? u : nullptr, xnext, cost, DIFF ? &kd : nullptr);
     double *xn = a.xnext + tb * NX;
     ASLR_UNROLL for (int i = 0; i < NX; ++i) xn[i] = xnext[i];
     a.cost[tb] = cost;
@@ -145,7 +148,10 @@ __global__ void __launch_bounds__(64) dam_eval_kernel(const DevDesc *desc, int m
   ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = uin[(size_t)p * NU + i];
   KnotDiff<NJ, NU> kd;
   using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
-  knot_eval<NJ, DAM, kEvalDiff, CH>(D, dm, frame_ref, x, u, xnext, c, &kd, xo);
+  const typename CH::Consts cc(D);
+  ModelRegs<NJ, NU> mr;
+  mr.load(dm);
+  knot_eval<NJ, DAM, kEvalDiff, CH>(cc, mr, dm, frame_ref, x, u, xnext, c, &kd, xo);
   if (cost) cost[p] = c;
   if (xout) {
     ASLR_UNROLL for (int i = 0; i < NV; ++i) xout[(size_t)p * NV + i] = xo[i];

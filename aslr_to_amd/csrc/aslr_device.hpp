@@ -386,11 +386,16 @@ ASLR_DEV void rnea(const aslr_chain_t &c, const Kin<NJ> &k, const double *v, con
 // Chain policy: generic fixed-base revolute chain in 3-D.
 template <int NJ>
 struct Chain3D {
+  // chain constants: the generic path reads the (large) table in place
+  struct Consts {
+    const aslr_chain_t *c;
+    ASLR_DEV explicit Consts(const DevDesc &D) : c(&D.chain) {}
+  };
   const aslr_chain_t &c;
   Kin<NJ> kin;
   RneaWs<NJ> ws;
   SE3d oMi[NJ];
-  ASLR_DEV explicit Chain3D(const DevDesc &D) : c(D.chain) {}
+  ASLR_DEV explicit Chain3D(const Consts &cc) : c(*cc.c) {}
 
   ASLR_DEV void setup(const double *q) {
     ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
@@ -511,12 +516,25 @@ ASLR_DEV PV p_inertia(double m, double cx, double cy, double izz, PV v) {
 
 template <int NJ>
 struct ChainPlanar {
-  const PlanarChain &pc;
+  // chain constants copied once into registers (uniform values end up in SGPRs), so a kernel that
+  // evaluates many knots per lane does not re-fetch them every knot
+  struct Consts {
+    double gx, gy, cphi[NJ], sphi[NJ], px[NJ], py[NJ], pz[NJ], m[NJ], cx[NJ], cy[NJ], izz[NJ];
+    ASLR_DEV explicit Consts(const DevDesc &D) {
+      const PlanarChain &p = D.planar;
+      gx = p.gx; gy = p.gy;
+      ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+        cphi[i] = p.cphi[i]; sphi[i] = p.sphi[i]; px[i] = p.px[i]; py[i] = p.py[i]; pz[i] = p.pz[i];
+        m[i] = p.m[i]; cx[i] = p.cx[i]; cy[i] = p.cy[i]; izz[i] = p.izz[i];
+      }
+    }
+  };
+  const Consts &pc;
   PX X[NJ];
   PV v_[NJ], h_[NJ], F_[NJ], Xv_[NJ], Xa_[NJ];
   double qd_[NJ];
   double cT[NJ], sT[NJ], Px[NJ], Py[NJ]; // world angle / position of each joint frame
-  ASLR_DEV explicit ChainPlanar(const DevDesc &D) : pc(D.planar) {}
+  ASLR_DEV explicit ChainPlanar(const Consts &cc) : pc(cc) {}
 
   ASLR_DEV void setup(const double *q) {
     ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
@@ -767,6 +785,19 @@ ASLR_DEV void spd_inverse_fast(const double (&A)[N][N], double (&Ainv)[N][N]) {
   }
 }
 
+// dynamics constants of one action model held in registers
+template <int NJ, int NU>
+struct ModelRegs {
+  double dt, K[NJ][NJ], Binv[NJ][NJ], S[NJ][NU];
+  ASLR_DEV void load(const DevModel &dm) {
+    dt = dm.m.dt;
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) { K[i][j] = dm.m.K[i * NJ + j]; Binv[i][j] = dm.Binv[i * NJ + j]; }
+      ASLR_UNROLL for (int j = 0; j < NU; ++j) S[i][j] = dm.m.S[i * NU + j];
+    }
+  }
+};
+
 // what knot_eval computes
 constexpr int kEvalDyn = 1;  // xnext (dynamics + Euler step)
 constexpr int kEvalCost = 2; // cost
@@ -776,7 +807,8 @@ constexpr int kEvalDiff = 4; // compact derivatives (implies both of the above)
 // u == nullptr selects the model's "u is None" default (terminal node).
 // CH is the chain policy (Chain3D / ChainPlanar); WHAT a mask of kEval* bits.
 template <int NJ, int DAM, int WHAT, class CH>
-ASLR_DEV void knot_eval(const DevDesc &D, const DevModel &dm, const double *frame_ref,
+ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, ModelDims<NJ, DAM>::nu> &mr,
+                        const DevModel &dm, const double *frame_ref,
                         const double (&x)[4 * NJ], const double *u_in, double (&xnext)[4 * NJ],
                         double &cost_out, KnotDiff<NJ, ModelDims<NJ, DAM>::nu> *kd,
                         double *xout_o = nullptr) {
@@ -794,7 +826,7 @@ ASLR_DEV void knot_eval(const DevDesc &D, const DevModel &dm, const double *fram
   double q[NJ], v[NJ], dqm[NJ];
   ASLR_UNROLL for (int i = 0; i < NJ; ++i) { q[i] = x[i]; v[i] = x[2 * NJ + i]; dqm[i] = x[i] - x[NJ + i]; }
 
-  CH ch(D);
+  CH ch(cc);
   ch.setup(q);
 
   if (DYN) {
@@ -808,7 +840,7 @@ ASLR_DEV void knot_eval(const DevDesc &D, const DevModel &dm, const double *fram
     } else {
       ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
         double s = 0.0;
-        ASLR_UNROLL for (int j = 0; j < NJ; ++j) { Kmat[i][j] = m.K[i * NJ + j]; s += m.S[i * NU + j] * u[j]; }
+        ASLR_UNROLL for (int j = 0; j < NJ; ++j) { Kmat[i][j] = mr.K[i][j]; s += mr.S[i][j] * u[j]; }
         tau_m[i] = s;
       }
     }
@@ -827,7 +859,7 @@ ASLR_DEV void knot_eval(const DevDesc &D, const DevModel &dm, const double *fram
       double s = 0.0, s2 = 0.0;
       ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
         s += Minv[i][j] * (-nle[j] - tau_c[j]);
-        s2 += dm.Binv[i * NJ + j] * (tau_m[j] + tau_c[j]);
+        s2 += mr.Binv[i][j] * (tau_m[j] + tau_c[j]);
       }
       xout[i] = s;
       xout[NJ + i] = s2;
@@ -836,7 +868,7 @@ ASLR_DEV void knot_eval(const DevDesc &D, const DevModel &dm, const double *fram
       ASLR_UNROLL for (int i = 0; i < 2 * NJ; ++i) xout_o[i] = xout[i];
     }
     // semi-implicit Euler (integrated_action.py:23-24)
-    const double dt = m.dt;
+    const double dt = mr.dt;
     ASLR_UNROLL for (int i = 0; i < 2 * NJ; ++i) {
       xnext[i] = x[i] + (x[2 * NJ + i] * dt + xout[i] * dt * dt);
       xnext[2 * NJ + i] = x[2 * NJ + i] + xout[i] * dt;
@@ -852,7 +884,7 @@ ASLR_DEV void knot_eval(const DevDesc &D, const DevModel &dm, const double *fram
             sq += Minv[i][l] * (-ddq[l][j] - Kmat[l][j]);
             sk += Minv[i][l] * Kmat[l][j];
             sv += Minv[i][l] * (-ddv[l][j]);
-            bk += dm.Binv[i * NJ + l] * Kmat[l][j];
+            bk += mr.Binv[i][l] * Kmat[l][j];
           }
           kd->Aqq[i][j] = sq; kd->Aqm[i][j] = sk; kd->Aqv[i][j] = sv; kd->Bk[i][j] = bk;
         }
@@ -862,14 +894,14 @@ ASLR_DEV void knot_eval(const DevDesc &D, const DevModel &dm, const double *fram
         ASLR_UNROLL for (int i = 0; i < NJ; ++i)
           ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
             kd->Ful[i][NJ + j] = Minv[i][j] * (-x[j] + x[NJ + j]);
-            kd->Fum[i][NJ + j] = dm.Binv[i * NJ + j] * (x[j] - x[NJ + j]);
-            kd->Fum[i][j] = dm.Binv[i * NJ + j];
+            kd->Fum[i][NJ + j] = mr.Binv[i][j] * (x[j] - x[NJ + j]);
+            kd->Fum[i][j] = mr.Binv[i][j];
           }
       } else if (NU > 1) {
         ASLR_UNROLL for (int i = 0; i < NJ; ++i)
           ASLR_UNROLL for (int j = 0; j < NU; ++j) {
             double s = 0.0;
-            ASLR_UNROLL for (int l = 0; l < NJ; ++l) s += dm.Binv[i * NJ + l] * m.S[l * NU + j];
+            ASLR_UNROLL for (int l = 0; l < NJ; ++l) s += mr.Binv[i][l] * mr.S[l][j];
             kd->Fum[i][j] = s;
           }
       }

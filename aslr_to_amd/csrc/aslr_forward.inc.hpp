@@ -45,8 +45,11 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
     const double *x0 = a.x0 + (size_t)b * NX;
     ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = x0[i];
   }
+  const typename CH::Consts cc(D);
+  ModelRegs<NJ, NU> mr;
+  int m_loaded = -1;
   // inputs of knot 0
-  double xr[NX], ur[NU], kr[NU], fg[NX], vf[NX];
+  double xr[NX], ur[NU], kr[NU], fg[NX], vf[NX], Kr[NU][NX];
   int mi;
   auto load_knot = [&](int t) {
     const size_t tb = (size_t)t * B + b;
@@ -56,6 +59,9 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
     mi = a.node_model[t];
     if (t < T) {
       ASLR_UNROLL for (int i = 0; i < NU; ++i) { ur[i] = a.us[tb * NU + i]; kr[i] = a.kff[tb * NU + i]; }
+      const double *Kg = a.kgain + tb * NU * NX;
+      ASLR_UNROLL for (int i = 0; i < NU; ++i)
+        ASLR_UNROLL for (int jx = 0; jx < NX; ++jx) Kr[i][jx] = Kg[i * NX + jx];
     }
   };
   ASLR_UNROLL for (int i = 0; i < NX; ++i) { fg[i] = 0.0; vf[i] = 0.0; }
@@ -76,13 +82,10 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
     }
     if (t == T) break;
     double u[NU];
-    {
-      const double *Kr = a.kgain + tb * NU * NX;
-      ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-        double s = ur[i] - kr[i] * alpha;
-        ASLR_UNROLL for (int jx = 0; jx < NX; ++jx) s -= Kr[i * NX + jx] * dx[jx];
-        u[i] = s;
-      }
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+      double s = ur[i] - kr[i] * alpha;
+      ASLR_UNROLL for (int jx = 0; jx < NX; ++jx) s -= Kr[i][jx] * dx[jx];
+      u[i] = s;
     }
     const int m_now = mi;
     if (box && lim.has[m_now]) {
@@ -94,8 +97,9 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
     }
     load_knot(t + 1); // in flight while the dynamics of knot t computes
     const DevModel &dm = D.models[m_now];
+    if (m_now != m_loaded) { mr.load(dm); m_loaded = m_now; } // wave-uniform
     double xnext[NX], c;
-    knot_eval<NJ, DAM, kEvalDyn, CH>(D, dm, nullptr, x, u, xnext, c, nullptr);
+    knot_eval<NJ, DAM, kEvalDyn, CH>(cc, mr, dm, nullptr, x, u, xnext, c, nullptr);
     double mx = 0.0;
     ASLR_UNROLL for (int i = 0; i < NX; ++i) { mx += fabs(xnext[i]); x[i] = xnext[i]; }
     if (is_bad(mx)) fail = true; // NaN / Inf / >= 1e30 in the state ("forward_error")
@@ -128,7 +132,10 @@ __global__ void __launch_bounds__(256) trial_cost_kernel(KArgs a, SolverDev sp) 
   const DevDesc &D = *a.desc;
   const DevModel &dm = D.models[a.node_model[t]];
   const double *fref = a.frame_ref ? a.frame_ref + 12 * (size_t)b : nullptr;
-  knot_eval<NJ, DAM, kEvalCost, CH>(D, dm, fref, x, t < T ? u : nullptr, xnext, c, nullptr);
+  const typename CH::Consts cc(D);
+  ModelRegs<NJ, NU> mr;
+  mr.load(dm);
+  knot_eval<NJ, DAM, kEvalCost, CH>(cc, mr, dm, fref, x, t < T ? u : nullptr, xnext, c, nullptr);
   a.cost_try[(size_t)ai * TB1 + tb] = c;
 }
 

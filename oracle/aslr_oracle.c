@@ -824,6 +824,12 @@ int aslr_cpu_calc(const aslr_problem_desc_t *d, const double *xs, const double *
 /* ======================================================================================= */
 /* diagnostics (serial runs only): number of calls, projected-Newton iterations, line-search trials */
 static long long g_qp_calls, g_qp_iters, g_qp_trials, g_qp_maxed;
+static long long g_qp_hist_it[16], g_qp_hist_tr[32];
+void aslr_cpu_boxqp_hist(long long *it16, long long *tr32, int reset) {
+  for (int i = 0; i < 16; ++i) it16[i] = g_qp_hist_it[i];
+  for (int i = 0; i < 32; ++i) tr32[i] = g_qp_hist_tr[i];
+  if (reset) { memset(g_qp_hist_it, 0, sizeof g_qp_hist_it); memset(g_qp_hist_tr, 0, sizeof g_qp_hist_tr); }
+}
 void aslr_cpu_boxqp_stats(long long *out4, int reset) {
   out4[0] = g_qp_calls; out4[1] = g_qp_iters; out4[2] = g_qp_trials; out4[3] = g_qp_maxed;
   if (reset) g_qp_calls = g_qp_iters = g_qp_trials = g_qp_maxed = 0;
@@ -837,6 +843,7 @@ int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, co
   int nf = 0, nc = 0, k;
   for (int i = 0; i < n; ++i) x[i] = fmax(fmin(x[i], ub[i]), lb[i]);
   g_qp_calls++;
+  long long tr0 = g_qp_trials;
   for (k = 0; k < maxiter; ++k) {
     g_qp_iters++;
     nf = nc = 0;
@@ -863,6 +870,8 @@ int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, co
         if (spd_inverse(nf, L, Hff_inv)) { *nf_o = nf; *nc_o = nc; return -1; }
       }
       *nf_o = nf; *nc_o = nc;
+      g_qp_hist_it[k < 15 ? k : 15]++;
+      { long long tr = g_qp_trials - tr0; g_qp_hist_tr[tr < 31 ? tr : 31]++; }
       return k;
     }
     for (int i = 0; i < nf; ++i) Hff[i * nf + i] += reg;
