@@ -133,7 +133,7 @@ EXPORTED_SYMBOLS = [
     "aslr_abi_version", "aslr_sizeof", "aslr_record_len", "aslr_solver_params_default",
     "aslr_workspace_bytes", "aslr_problem_create", "aslr_problem_destroy", "aslr_problem_region",
     "aslr_calc", "aslr_calc_diff", "aslr_backward_pass", "aslr_forward_pass", "aslr_solve",
-    "aslr_iterate", "aslr_iterate_timed", "aslr_finalize", "aslr_count_active", "aslr_dam_eval", "aslr_last_error",
+    "aslr_iterate", "aslr_iterate_timed", "aslr_finalize", "aslr_count_active", "aslr_dam_eval", "aslr_quasi_static", "aslr_last_error",
 ]
 
 
@@ -186,6 +186,8 @@ def load_library():
     lib.aslr_count_active.argtypes = [vp, vp, C.POINTER(i32)]
     lib.aslr_dam_eval.restype = C.c_int
     lib.aslr_dam_eval.argtypes = [vp, i32, i32] + [vp] * 11 + [vp]
+    lib.aslr_quasi_static.restype = C.c_int
+    lib.aslr_quasi_static.argtypes = [vp, i32, C.c_double, vp, vp]
     lib.aslr_last_error.restype = C.c_char_p
     if lib.aslr_abi_version() != ABI_VERSION:
         raise ImportError("aslr_to_amd: ABI version mismatch between %s and the Python layer" % path)

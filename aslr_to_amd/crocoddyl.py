@@ -119,8 +119,21 @@ class ShootingProblem(object):
         torch.cuda.synchronize(e.device)
         return [x for x in xs[0].cpu().numpy()] if self.batch == 1 else xs.clone()
 
-    def quasiStatic(self, xs):
-        raise NotImplementedError("ShootingProblem.quasiStatic is a SURVEY.md 8(f) 'next' row")
+    def quasiStatic(self, xs, maxiter=100, tol=1e-9):
+        """us[t] holding xs[t] still under node t's model (examples/two_dof_sea.py:78); xs has T entries."""
+        import torch
+        e = self.engine
+        xs = np.asarray(xs, dtype=np.float64) if not torch.is_tensor(xs) else xs
+        x = torch.as_tensor(xs, dtype=torch.float64, device=e.device)
+        if x.dim() == 2:
+            x = x.unsqueeze(0).expand(self.batch, -1, -1)
+        X = e.region(_abi.R_XS)
+        X[:self.T].copy_(x[:, :self.T].permute(1, 0, 2))
+        e.region(_abi.R_US).zero_()
+        e.quasi_static(maxiter, tol)
+        torch.cuda.synchronize(e.device)
+        U = e.region(_abi.R_US).permute(1, 0, 2)
+        return [u for u in U[0].cpu().numpy()] if self.batch == 1 else U.clone()
 
     @property
     def runningDatas(self):

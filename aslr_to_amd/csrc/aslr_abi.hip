@@ -478,6 +478,15 @@ int aslr_dam_eval(aslr_problem_t *p, int32_t model_index, int32_t n, const doubl
   return ASLR_E_INVALID;
 }
 
+int aslr_quasi_static(aslr_problem_t *p, int32_t maxiter, double tol, int32_t *iters_dev, void *stream) {
+  if (!p || maxiter <= 0) return ASLR_E_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p->nj == 2) return launch_quasi_static_nj2(p->k, p->dam, maxiter, tol, iters_dev, st);
+  if (p->nj == 7) return launch_quasi_static_nj7(p->k, p->dam, maxiter, tol, iters_dev, st);
+  snprintf(g_err, sizeof g_err, "unsupported nj=%d", p->nj);
+  return ASLR_E_INVALID;
+}
+
 const char *aslr_last_error(void) { return g_err; }
 
 } // extern "C"

@@ -132,6 +132,69 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
   }
 }
 
+// ShootingProblem.quasiStatic (examples/two_dof_sea.py:78): Crocoddyl's base-class
+// Gauss-Newton per running node, u = 0; repeat { calc, calcDiff; du = -pinv(Fu) (xnext - x); u += du }
+// until |du| <= tol or maxiter.  One lane per (trajectory, node).  pinv(Fu) = (Fu^T Fu)^-1 Fu^T, valid for
+// the full-column-rank Fu of the SEA models (the only example whose quasi-static result is used); a
+// rank-deficient Fu^T Fu (e.g. VSA at q_l = q_m, where the stiffness columns vanish) leaves u untouched
+// and reports -1 iterations for that node.
+template <int NJ, int DAM, bool PLANAR>
+__global__ void __launch_bounds__(64) quasi_static_kernel(KArgs a, int maxiter, double tol, int32_t *iters_out) {
+  constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu, NV = 2 * NJ;
+  using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
+  const int B = a.B, T = a.T, t = blockIdx.y;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B || t >= T) return;
+  const size_t tb = (size_t)t * B + b;
+  const DevDesc &D = *a.desc;
+  const DevModel &dm = D.models[a.node_model[t]];
+  const double *fref = a.frame_ref ? a.frame_ref + 12 * (size_t)b : nullptr;
+  const typename CH::Consts cc(D);
+  ModelRegs<NJ, NU> mr;
+  mr.load(dm);
+  double x[NX], u[NU];
+  ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = a.xs[tb * NX + i];
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = 0.0;
+  int it = 0;
+  bool singular = false;
+  for (; it < maxiter; ++it) {
+    double xnext[NX], c;
+    KnotDiff<NJ, NU> kd;
+    knot_eval<NJ, DAM, kEvalDiff, CH>(cc, mr, dm, fref, x, u, xnext, c, &kd);
+    // Fu = dt [dt A_u ; A_u] (integrated_action.py:36-37); rows: positions (link, motor), velocities
+    const double dt = mr.dt;
+    double A[NU][NU], rhs[NU];
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+      double r = 0.0;
+      ASLR_UNROLL for (int l = 0; l < NV; ++l) {
+        const double au = l < NJ ? kd.Ful[l < NJ ? l : 0][i] : kd.Fum[l >= NJ ? l - NJ : 0][i];
+        const double fp = dt * (au * dt), fv = dt * au;
+        r += fp * (xnext[l] - x[l]) + fv * (xnext[NV + l] - x[NV + l]);
+      }
+      rhs[i] = -r;
+      ASLR_UNROLL for (int j = 0; j < NU; ++j) {
+        double s2 = 0.0;
+        ASLR_UNROLL for (int l = 0; l < NV; ++l) {
+          const double ai = l < NJ ? kd.Ful[l < NJ ? l : 0][i] : kd.Fum[l >= NJ ? l - NJ : 0][i];
+          const double aj = l < NJ ? kd.Ful[l < NJ ? l : 0][j] : kd.Fum[l >= NJ ? l - NJ : 0][j];
+          s2 += (dt * (ai * dt)) * (dt * (aj * dt)) + (dt * ai) * (dt * aj);
+        }
+        A[i][j] = s2;
+      }
+    }
+    double rinv[NU];
+    if (chol_r<NU>(A, rinv)) { singular = true; break; }
+    chol_solve_r<NU>(A, rinv, rhs);
+    double nrm = 0.0;
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) { u[i] += rhs[i]; nrm += rhs[i] * rhs[i]; }
+    if (sqrt(nrm) <= tol) break;
+  }
+  if (!singular) {
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) a.us[tb * NU + i] = u[i];
+  }
+  if (iters_out) iters_out[tb] = singular ? -1 : it;
+}
+
 // DAM-level evaluation of arbitrary points (aslr_dam_eval): dense continuous blocks, one lane per point
 template <int NJ, int DAM, bool PLANAR>
 __global__ void __launch_bounds__(64) dam_eval_kernel(const DevDesc *desc, int mi, const double *frame_ref, int n,

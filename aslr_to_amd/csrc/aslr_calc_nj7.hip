@@ -30,4 +30,15 @@ int launch_dam_eval_nj7(const KArgs &k, int dam, int mi, int n, const double *x,
   return ASLR_E_INVALID;
 }
 
+int launch_quasi_static_nj7(const KArgs &k, int dam, int maxiter, double tol, int32_t *iters, hipStream_t st) {
+  dim3 grid((k.B + 63) / 64, k.T), block(64);
+  if (dam == ASLR_DAM_SEA) {
+    hipLaunchKernelGGL((quasi_static_kernel<7, ASLR_DAM_SEA, false>), grid, block, 0, st, k, maxiter, tol, iters);
+    HIP_TRY(hipGetLastError());
+    return ASLR_OK;
+  }
+  snprintf(err_buf(), kErrLen, "quasi_static: unsupported (nj=7, dam=%d)", dam);
+  return ASLR_E_INVALID;
+}
+
 } // namespace aslr

@@ -155,6 +155,14 @@ class Engine(object):
                    "aslr_iterate_timed")
         return tuple(float(v) for v in ms)
 
+    def quasi_static(self, maxiter=100, tol=1e-9):
+        """Fill US with the quasi-static controls of the states in XS; returns the [T, B] iteration counts."""
+        torch = _torch()
+        iters = torch.zeros((self.T, self.B), dtype=torch.int32, device=self.device)
+        _abi.check(self.lib.aslr_quasi_static(self.handle, int(maxiter), float(tol), C.c_void_p(iters.data_ptr()),
+                                              self._stream()), "aslr_quasi_static")
+        return iters
+
     def finalize(self):
         _abi.check(self.lib.aslr_finalize(self.handle, self._stream()), "aslr_finalize")
 

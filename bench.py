@@ -114,12 +114,15 @@ def main():
     torch.cuda.synchronize(dev)
     stats = dist.all_reduce_stats(dist.local_stats(e))  # the ONE collective of a solve (RCCL over xGMI)
 
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     knot_steps = Bg * world * T * args.steps
     value = knot_steps / elapsed
     p1, p2, p3 = algorithmic_bytes(e.nx, e.nu)
-    names = ["calc_kernel", "backward_kernel", "forward_kernel"]
+    names = ["calc_kernel", "backward_kernel", "forward (rollout + trial_cost + sum_cost + select kernels)"]
     # the sequential line search of the algorithm needs (accepted index + 1) trials; the kernel evaluates
     # all 10 step lengths at once, but only the required ones count as algorithmic traffic
     trials = stats["trials_sum"] / max(stats["iters_sum"], 1)

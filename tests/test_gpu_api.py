@@ -196,3 +196,32 @@ def test_rollout_and_problem_calc_api():
     np.testing.assert_allclose(datas[3].xnext, xs[4], atol=1e-13)
     problem.calcDiff(xs, us)
     assert datas[0].Fx.shape == (8, 8) and problem.terminalData.Lxx.shape == (8, 8)
+
+
+def test_quasi_static_matches_oracle_and_holds_the_state(oracle):
+    """ShootingProblem.quasiStatic (examples/two_dof_sea.py:77-78): the SEA example's warm start."""
+    sc = scenarios.two_dof_sea(B=1, T=10)
+    problem = crocoddyl.ShootingProblem(sc["x0"][0], sc["running"], sc["terminal"])
+    rng = np.random.default_rng(3)
+    q = rng.uniform(-0.5, 0.5, 2)
+    x = np.concatenate([q, q + 0.05, np.zeros(4)])
+    us = problem.quasiStatic([x] * problem.T)
+    assert len(us) == 10
+    u_ref, it = oracle.quasi_static(problem.lowered, 0, x)
+    assert it >= 0
+    np.testing.assert_allclose(us[0], u_ref, rtol=1e-8, atol=1e-10)
+    # Gauss-Newton fixed point: Fu^T (xnext - x) = 0
+    k = oracle.knot(problem.lowered, 0, x, us[0])
+    assert np.abs(k["Fu"].T.dot(k["xnext"] - x)).max() < 1e-8
+    # SEA example flow: warm start, then FDDP (examples/two_dof_sea.py:77-81)
+    x0 = sc["x0"][0]
+    xs0 = [x0] * (problem.T + 1)
+    us0 = problem.quasiStatic([x0] * problem.T)
+    solver = crocoddyl.SolverFDDP(problem)
+    solver.th_stop = 1e-7
+    assert solver.solve(xs0, us0, 100)
+    sp = _abi.default_solver_params(_abi.SOLVER_FDDP)
+    sp.maxiter, sp.th_stop = 100, 1e-7
+    ref = oracle.solve(problem.lowered, sp, xs=np.array(xs0)[:, None, :], us=np.array(us0)[:, None, :])
+    assert np.abs(np.array(solver.xs) - ref["xs"][:, 0]).max() < 1e-6
+    assert abs(solver.cost - ref["traj_f"][_abi.TF_COST][0]) < 1e-4

@@ -150,6 +150,8 @@ SOLVE_CASES = [
     ("two_dof_sea", dict(B=6, T=100), "SolverFDDP"),
     ("double_pendulum", dict(T=10), "SolverDDP"),
     ("double_pendulum", dict(T=10), "SolverFDDP"),
+    ("talos_arm_sea", dict(B=3, T=30), "SolverDDP"),   # C5 model at a size the oracle solves in seconds
+    ("talos_arm_sea", dict(B=2, T=30), "SolverFDDP"),
 ]
 
 
