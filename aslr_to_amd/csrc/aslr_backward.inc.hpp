@@ -44,6 +44,7 @@ ASLR_DEV bool chol_rs(double (&A)[N][N], double (&rinv)[N]) {
 // zeros changes no bits, so every quantity equals what the index-set formulation computes.  All teams of
 // a wave step together (wave-uniform loop control by ballot); a team that has converged keeps its
 // state through selects and its factor is simply rebuilt from its (final) mask.
+// A team whose line search rejects all step lengths stops at once (its state can no longer change).
 // On exit: x, the clamped flags of the final active set, and kcol <- Quu_inv kcol where Quu_inv is
 // Hff^-1 on the free block and zero elsewhere (Crocoddyl forms Hff^-1 explicitly and multiplies; solving
 // with the same factor differs by rounding only).
@@ -123,7 +124,9 @@ ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const doub
       found = found || take;
       if (__ballot(!found) == 0ull) break;
     }
-    finished = fin_now || cbad;
+    // No step length accepted: x is unchanged, so every remaining iteration would recompute the same
+    // gradient, active set and rejected steps and return this x.  Stop here with that result.
+    finished = fin_now || cbad || !found;
   }
   // factor of the final free block: the one at hand unless the active set changed in the last step
   bool stale = false;
@@ -159,7 +162,9 @@ struct BwdCfg {
   static constexpr int NPRE = (REC / 2 + TEAM - 1) / TEAM; // double2 prefetch registers per lane
 };
 
-template <int NX, int NU, int HS, int TPWA>
+// BOX: SolverBoxDDP gains may be needed (solver is BoxDDP); GAPS: infeasible candidates may be present
+// (gap terms, FDDP expected-improvement terms).  A wave whose trajectories need neither runs the lean variant.
+template <int NX, int NU, int HS, int TPWA, bool BOX, bool GAPS>
 __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
   using C = BwdCfg<NX, NU, HS, TPWA>;
   constexpr int NXP = C::NXP, TEAM = C::TEAM, TPW = C::TPW, RPL = C::RPL, REC = C::REC;
@@ -206,9 +211,9 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
   bool need = team_valid && !done;
   if (__ballot(need) == 0ull) return;
   double xreg = TF[ASLR_TF_XREG * B + b];
-  const bool fddp = sp.solver == ASLR_SOLVER_FDDP;
-  const bool box = sp.solver == ASLR_SOLVER_BOXDDP && feasible;
-  const bool gaps_on = !feasible;
+  const bool fddp = GAPS && sp.solver == ASLR_SOLVER_FDDP;
+  const bool box = BOX && sp.solver == ASLR_SOLVER_BOXDDP && feasible;
+  const bool gaps_on = GAPS && !feasible;
   const unsigned long long team_mask = (TEAM == 64 ? ~0ull : ((1ull << TEAM) - 1ull)) << (team * TEAM);
 
   // one-hot selectors of this lane's diagonal / control row (FMA instead of compare + select in the loop)
@@ -249,27 +254,29 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       ASLR_UNROLL for (int l = 0; l < NX; ++l) pvec[l] = VxL[l];
     }
     // ---- prefetch for knot T-1: record, model index, box-QP inputs, gap ----
-    double2 pre[C::NPRE];
+    double prx[C::NPRE], pry[C::NPRE];
     double pre_u[NU], pre_k[NU], pre_f[NX];
     int pre_m = 0;
     ASLR_UNROLL for (int c = 0; c < NU; ++c) { pre_u[c] = 0.0; pre_k[c] = 0.0; }
     ASLR_UNROLL for (int r = 0; r < NX; ++r) pre_f[r] = 0.0;
-    auto prefetch = [&](int t) {
-      const size_t tb = (size_t)t * B + b;
-      const double2 *src = reinterpret_cast<const double2 *>(a.deriv + tb * REC);
-      ASLR_UNROLL for (int i = 0; i < C::NPRE; ++i) {
-        const int idx = lt + TEAM * i;
-        if (C::NPRE * TEAM == REC / 2 || idx < REC / 2) pre[i] = src[idx];
-      }
-      pre_m = a.node_model[t];
-      if (box) {
-        ASLR_UNROLL for (int c = 0; c < NU; ++c) { pre_u[c] = a.us[tb * NU + c]; pre_k[c] = a.kff[tb * NU + c]; }
-      }
-      if (gaps_on) {
-        ASLR_UNROLL for (int r = 0; r < NX; ++r) pre_f[r] = a.gaps[tb * NX + r];
-      }
-    };
-    prefetch(T - 1);
+    // (a macro, not a by-reference lambda: the closure kept `pre` in scratch memory)
+#define ASLR_BWD_PREFETCH(tt)                                                                          \
+    do {                                                                                               \
+      const size_t tbp = (size_t)(tt) * B + b;                                                         \
+      const double2 *src = reinterpret_cast<const double2 *>(a.deriv + tbp * REC);                     \
+      ASLR_UNROLL for (int i = 0; i < C::NPRE; ++i) {                                                  \
+        const int idx = lt + TEAM * i;                                                                 \
+        if (C::NPRE * TEAM == REC / 2 || idx < REC / 2) { const double2 v2 = src[idx]; prx[i] = v2.x; pry[i] = v2.y; } \
+      }                                                                                                \
+      pre_m = a.node_model[tt];                                                                        \
+      if (box) {                                                                                       \
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) { pre_u[c] = a.us[tbp * NU + c]; pre_k[c] = a.kff[tbp * NU + c]; } \
+      }                                                                                                \
+      if (gaps_on) {                                                                                   \
+        ASLR_UNROLL for (int r = 0; r < NX; ++r) pre_f[r] = a.gaps[tbp * NX + r];                      \
+      }                                                                                                \
+    } while (0)
+    ASLR_BWD_PREFETCH(T - 1);
     for (int t = T - 1; t >= 0; --t) {
       const size_t tb = (size_t)t * B + b;
       // stage the record in LDS, take this knot's small inputs, start the next loads
@@ -277,7 +284,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         double2 *dst = reinterpret_cast<double2 *>(rec);
         ASLR_UNROLL for (int i = 0; i < C::NPRE; ++i) {
           const int idx = lt + TEAM * i;
-          if (C::NPRE * TEAM == REC / 2 || idx < REC / 2) dst[idx] = pre[i];
+          if (C::NPRE * TEAM == REC / 2 || idx < REC / 2) { double2 v2; v2.x = prx[i]; v2.y = pry[i]; dst[idx] = v2; }
         }
       }
       double ut[NU], k0[NU], fg[NX];
@@ -285,7 +292,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       ASLR_UNROLL for (int r = 0; r < NX; ++r) fg[r] = pre_f[r];
       const int mi = pre_m;
       wave_sync();
-      if (t > 0 && !(sp.debug & 2)) prefetch(t - 1);
+      if (t > 0 && !(sp.debug & 2)) ASLR_BWD_PREFETCH(t - 1);
 
       // ---- step 1: A = Fx^T P (my rows of column jj), Bc = Fu^T P (column jj), Qx, Qu ----
       double Fxcol[NX], Fucol[NX];
@@ -379,13 +386,13 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         }
         if (!any_clamped && !failed && sp.boxqp_reg == 0.0 && gnorm0 <= sp.boxqp_th_grad) {
           ASLR_UNROLL for (int c = 0; c < NU; ++c) kv[c] = -x0[c]; // (a)
-        } else if (!any_clamped && interior) {
+        } else if ((!any_clamped && interior) || (sp.debug & 4)) {
           // (b): kv, Kc already hold the result
         } else {
           double xq[NU];
           bool cm[NU];
           ASLR_UNROLL for (int c = 0; c < NU; ++c) { xq[c] = k0[c]; Kc[c] = Qux[c]; }
-          if (boxqp<NU>(Quu, qu, lb, ub, xq, cm, Kc, sp.boxqp_maxiter, sp.boxqp_th_acceptstep, sp.boxqp_th_grad,
+          if (boxqp<NU>(Quu, qu, lb, ub, xq, cm, Kc, (sp.debug & 8) ? 1 : ((sp.debug & 16) ? 2 : sp.boxqp_maxiter), sp.boxqp_th_acceptstep, sp.boxqp_th_grad,
                         sp.boxqp_reg)) failed = true;
           ASLR_UNROLL for (int c = 0; c < NU; ++c) {
             kv[c] = -xq[c];
@@ -503,12 +510,17 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
   }
 }
 
+// `all_feasible`: the caller knows every trajectory of the shard is feasible (no gap terms needed)
 template <int NX, int NU, int HS, int TPWA = 0>
-int launch_backward_t(const KArgs &k, const SolverDev &sd, const ModelLimits &lim, hipStream_t st) {
+int launch_backward_t(const KArgs &k, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st) {
   using C = BwdCfg<NX, NU, HS, TPWA>;
   const int blocks = (k.B + C::TPW - 1) / C::TPW;
   const size_t lds = (size_t)C::TPW * C::LDS_TEAM * sizeof(double);
-  hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA>), dim3(blocks), dim3(64), lds, st, k, sd, lim);
+  const bool box = sd.solver == ASLR_SOLVER_BOXDDP;
+  if (box && !all_feasible) hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, true, true>), dim3(blocks), dim3(64), lds, st, k, sd, lim);
+  else if (box) hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, true, false>), dim3(blocks), dim3(64), lds, st, k, sd, lim);
+  else if (!all_feasible) hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, false, true>), dim3(blocks), dim3(64), lds, st, k, sd, lim);
+  else hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, false, false>), dim3(blocks), dim3(64), lds, st, k, sd, lim);
   HIP_TRY(hipGetLastError());
   return ASLR_OK;
 }

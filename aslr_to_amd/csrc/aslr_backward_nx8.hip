@@ -2,14 +2,14 @@
 #include "aslr_backward.inc.hpp"
 
 namespace aslr {
-int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, hipStream_t st) {
-  if (nu == 2) return hs == 2 ? launch_backward_t<8, 2, 2>(k, sd, lim, st) : launch_backward_t<8, 2, 1>(k, sd, lim, st);
+int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st) {
+  if (nu == 2) return hs == 2 ? launch_backward_t<8, 2, 2>(k, sd, lim, all_feasible, st) : launch_backward_t<8, 2, 1>(k, sd, lim, all_feasible, st);
   if (nu == 4) {
     const char *e = getenv("ASLR_BWD_TPW");
     const int tpw = e ? atoi(e) : 0;
-    if (hs == 2 && tpw == 2) return launch_backward_t<8, 4, 2, 2>(k, sd, lim, st);
-    if (hs == 2 && tpw == 1) return launch_backward_t<8, 4, 2, 1>(k, sd, lim, st);
-    return hs == 2 ? launch_backward_t<8, 4, 2>(k, sd, lim, st) : launch_backward_t<8, 4, 1>(k, sd, lim, st);
+    if (hs == 2 && tpw == 2) return launch_backward_t<8, 4, 2, 2>(k, sd, lim, all_feasible, st);
+    if (hs == 2 && tpw == 1) return launch_backward_t<8, 4, 2, 1>(k, sd, lim, all_feasible, st);
+    return hs == 2 ? launch_backward_t<8, 4, 2>(k, sd, lim, all_feasible, st) : launch_backward_t<8, 4, 1>(k, sd, lim, all_feasible, st);
   }
   snprintf(err_buf(), kErrLen, "backward: unsupported (nx=8, nu=%d)", nu);
   return ASLR_E_INVALID;

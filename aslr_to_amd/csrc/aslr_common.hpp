@@ -76,8 +76,8 @@ int launch_dam_eval_nj7(const KArgs &k, int dam, int mi, int n, const double *x,
                         double *Luu, hipStream_t st);
 int launch_quasi_static_nj2(const KArgs &k, int dam, int maxiter, double tol, int32_t *iters, hipStream_t st);
 int launch_quasi_static_nj7(const KArgs &k, int dam, int maxiter, double tol, int32_t *iters, hipStream_t st);
-int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, hipStream_t st);
-int launch_backward_nx28(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, hipStream_t st);
+int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st);
+int launch_backward_nx28(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st);
 int launch_forward_nj2(const KArgs &k, int dam, const SolverDev &sd, const ModelLimits &lim, hipStream_t st);
 int launch_forward_nj7(const KArgs &k, int dam, const SolverDev &sd, const ModelLimits &lim, hipStream_t st);
 

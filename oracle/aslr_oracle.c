@@ -823,8 +823,9 @@ int aslr_cpu_calc(const aslr_problem_desc_t *d, const double *xs, const double *
 /* BoxQP (Tassa et al. 2014 projected Newton)                                */
 /* ======================================================================================= */
 /* diagnostics (serial runs only): number of calls, projected-Newton iterations, line-search trials */
-static long long g_qp_calls, g_qp_iters, g_qp_trials, g_qp_maxed;
-static long long g_qp_hist_it[16], g_qp_hist_tr[32];
+/* thread-local: OpenMP workers keep their own (the getters report the calling thread, i.e. serial runs) */
+static __thread long long g_qp_calls, g_qp_iters, g_qp_trials, g_qp_maxed;
+static __thread long long g_qp_hist_it[16], g_qp_hist_tr[32];
 void aslr_cpu_boxqp_hist(long long *it16, long long *tr32, int reset) {
   for (int i = 0; i < 16; ++i) it16[i] = g_qp_hist_it[i];
   for (int i = 0; i < 32; ++i) tr32[i] = g_qp_hist_tr[i];
@@ -871,7 +872,7 @@ int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, co
       }
       *nf_o = nf; *nc_o = nc;
       g_qp_hist_it[k < 15 ? k : 15]++;
-      { long long tr = g_qp_trials - tr0; g_qp_hist_tr[tr < 31 ? tr : 31]++; }
+      { long long tr = g_qp_trials - tr0; g_qp_hist_tr[tr < 0 ? 0 : (tr < 31 ? tr : 31)]++; }
       return k;
     }
     for (int i = 0; i < nf; ++i) Hff[i * nf + i] += reg;
@@ -896,6 +897,7 @@ int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, co
       fold += 0.5 * x[i] * s + q[i] * x[i];
     }
     double alpha = 1.0;
+    int accepted = 0;
     for (int a = 0; a < ASLR_NALPHA; ++a, alpha *= 0.5) {
       g_qp_trials++;
       for (int i = 0; i < n; ++i) xnew[i] = fmax(fmin(x[i] + alpha * dx[i], ub[i]), lb[i]);
@@ -908,8 +910,16 @@ int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, co
       }
       if (fold - fnew > th_acceptstep * gd) {
         memcpy(x, xnew, sizeof(double) * n);
+        accepted = 1;
         break;
       }
+    }
+    if (!accepted) {
+      /* x is unchanged: every remaining iteration of Crocoddyl's loop would recompute the same gradient,
+       * active set and rejected steps and finally return this x with this Hff^-1; return it now. */
+      g_qp_maxed++;
+      *nf_o = nf; *nc_o = nc;
+      return k + 1;
     }
   }
   *nf_o = nf; *nc_o = nc;
