@@ -263,10 +263,11 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
 #define ASLR_BWD_PREFETCH(tt)                                                                          \
     do {                                                                                               \
       const size_t tbp = (size_t)(tt) * B + b;                                                         \
-      const double2 *src = reinterpret_cast<const double2 *>(a.deriv + tbp * REC);                     \
+      typedef double nt_double2 __attribute__((ext_vector_type(2)));                                   \
+      const nt_double2 *src = reinterpret_cast<const nt_double2 *>(a.deriv + tbp * REC);               \
       ASLR_UNROLL for (int i = 0; i < C::NPRE; ++i) {                                                  \
         const int idx = lt + TEAM * i;                                                                 \
-        if (C::NPRE * TEAM == REC / 2 || idx < REC / 2) { const double2 v2 = src[idx]; prx[i] = v2.x; pry[i] = v2.y; } \
+        if (C::NPRE * TEAM == REC / 2 || idx < REC / 2) { const nt_double2 v2 = __builtin_nontemporal_load(src + idx); prx[i] = v2.x; pry[i] = v2.y; } \
       }                                                                                                \
       pre_m = a.node_model[tt];                                                                        \
       if (box) {                                                                                       \

@@ -3,7 +3,8 @@
 #include "aslr_common.hpp"
 
 #ifndef ASLR_CALC_WAVES
-#define ASLR_CALC_WAVES 2 // waves per SIMD the register allocator must allow (6400 waves at B = 4096, T = 100)
+#define ASLR_CALC_WAVES 1 // waves per SIMD the register allocator must allow: the kernel is bound by the record
+                          // write (734 MB per sweep at C3), 1 / 2 / 3 waves measured 171 / 177 / 244 us
 #endif
 
 namespace aslr {
@@ -124,7 +125,11 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
         double2 v2;
         v2.x = sm[k * kLdsStride + e];
         v2.y = sm[k * kLdsStride + e + 1];
-        *reinterpret_cast<double2 *>(rec0 + (size_t)k * REC + c * kChunk + e) = v2;
+        // streamed once, read once by the backward sweep: non-temporal
+        typedef double nt_double2 __attribute__((ext_vector_type(2)));
+        nt_double2 nv;
+        nv.x = v2.x; nv.y = v2.y;
+        __builtin_nontemporal_store(nv, reinterpret_cast<nt_double2 *>(rec0 + (size_t)k * REC + c * kChunk + e));
       }
     }
     wave_sync();
