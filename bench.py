@@ -45,6 +45,27 @@ def algorithmic_bytes(nx, nu):
     return p1, p2, p3
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (separate --pmc passes of this
+    same command, profiles/r01/bench_pmc.csv): WRITE_SIZE + 2 x FETCH_SIZE, both in KiB -- the gfx950
+    correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE counts wide coalesced reads at half).
+    None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01", "bench_pmc.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+    fetch = write = None
+    for r in csv.DictReader(open(path)):
+        if kernel_prefix in r["kernel"]:
+            if r["counter"] == "FETCH_SIZE":
+                fetch = float(r["median_per_dispatch"])
+            if r["counter"] == "WRITE_SIZE":
+                write = float(r["median_per_dispatch"])
+    if fetch is None or write is None:
+        return None
+    return (2.0 * fetch + write) * 1024.0
+
+
 def cpu_baseline(sc_fn, nthreads):
     """Oracle (CPU port) solving the first trajectories of the same batch in converge mode."""
     from aslr_to_amd import _abi, scenarios
@@ -123,6 +144,7 @@ def main():
     value = knot_steps / elapsed
     p1, p2, p3 = algorithmic_bytes(e.nx, e.nu)
     names = ["calc_kernel", "backward_kernel", "forward (rollout + trial_cost + sum_cost + select kernels)"]
+    pmc_names = ["aslr::calc_kernel<2, 1, true", "aslr::backward_kernel", "aslr::rollout_kernel"]
     # the sequential line search of the algorithm needs (accepted index + 1) trials; the kernel evaluates
     # all 10 step lengths at once, but only the required ones count as algorithmic traffic
     trials = stats["trials_sum"] / max(stats["iters_sum"], 1)
@@ -144,7 +166,9 @@ def main():
         "line_search_trials_per_iteration": trials,
         "kernel_ms": dict(zip(names, k_ms)),
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc_names[dom]),
+                     "traffic_note": "bytes per launch, rocprofv3 PMC summary committed under profiles/r01 (not live)",
+                     "algorithmic_bytes_per_launch": launch_bytes,
                      "algorithmic_bytes_per_knot_step": phase_bytes[dom],
                      "knot_steps_per_launch": Bg * T},
         "roofline_iteration": {"algorithmic_bytes_per_knot_step": p1 + p2 + p3,
