@@ -349,28 +349,13 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         qu[c] = QuL[c];
         ASLR_UNROLL for (int e = 0; e < NU; ++e) Quu[c][e] = QuuL[c * NU + e];
       }
-      // plain DDP gains: K = Quu^-1 Qux, k = Quu^-1 Qu
-      {
-        double L[NU][NU], rinv[NU];
-        ASLR_UNROLL for (int c = 0; c < NU; ++c)
-          ASLR_UNROLL for (int e = 0; e < NU; ++e) L[c][e] = Quu[c][e];
-        if (chol_rs<NU>(L, rinv)) failed = true;
-        ASLR_UNROLL for (int c = 0; c < NU; ++c) { kv[c] = qu[c]; Kc[c] = Qux[c]; }
-        chol_solve_r<NU>(L, rinv, kv);
-        chol_solve_r<NU>(L, rinv, Kc);
-      }
-      if (box && lim.has[mi]) {
-        // SolverBoxDDP::computeGains.  BoxQP's first iteration is replayed exactly (clamped warm start
-        // x0, gradient, active set).  When no index is clamped there, the QP iteration has two cheap
-        // outcomes that need no projected-Newton loop:
-        //   (a) |g(x0)|_inf <= th_grad: BoxQP returns x0 itself with every index free;
-        //   (b) otherwise it takes the full Newton step to the unconstrained minimiser -Quu^-1 Qu; when
-        //       that point is strictly inside the box the step is accepted at alpha = 1 and the next
-        //       gradient test passes, again with every index free.
-        // In both, Hff^-1 = Quu^-1, so K is the plain gain above.  Everything else runs BoxQP.
-        double lb[NU], ub[NU], x0[NU], g0[NU];
-        bool any_clamped = false, interior = !failed && sp.boxqp_reg == 0.0;
-        double gnorm0 = 0.0;
+      // SolverBoxDDP::computeGains starts by replaying BoxQP's first iteration exactly (clamped warm start
+      // x0, gradient, active set): cheap, and it tells which teams need the plain gains at all.
+      const bool boxed = box && lim.has[mi];
+      double lb[NU], ub[NU], x0[NU];
+      bool any_clamped = false;
+      double gnorm0 = 0.0;
+      if (boxed) {
         ASLR_UNROLL for (int c = 0; c < NU; ++c) {
           lb[c] = lim.lb[mi][c] - ut[c];
           ub[c] = lim.ub[mi][c] - ut[c];
@@ -379,15 +364,42 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         ASLR_UNROLL for (int c = 0; c < NU; ++c) {
           double sg = qu[c];
           ASLR_UNROLL for (int e = 0; e < NU; ++e) sg += Quu[c][e] * x0[e];
-          g0[c] = sg;
           any_clamped = any_clamped || (x0[c] == lb[c] && sg > 0.0) || (x0[c] == ub[c] && sg < 0.0);
           gnorm0 = fmax(gnorm0, fabs(sg));
+        }
+      }
+      // plain DDP gains K = Quu^-1 Qux, k = Quu^-1 Qu: needed by unconstrained nodes and by box nodes whose
+      // first active set is empty; skipped (wave-uniformly) when every team of the wave runs the QP
+      const bool need_plain = !boxed || !any_clamped;
+      bool plain_bad = false;
+      ASLR_UNROLL for (int c = 0; c < NU; ++c) { kv[c] = 0.0; Kc[c] = 0.0; }
+      if (__ballot(need_plain) != 0ull) {
+        double L[NU][NU], rinv[NU];
+        ASLR_UNROLL for (int c = 0; c < NU; ++c)
+          ASLR_UNROLL for (int e = 0; e < NU; ++e) L[c][e] = Quu[c][e];
+        plain_bad = chol_rs<NU>(L, rinv);
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) { kv[c] = qu[c]; Kc[c] = Qux[c]; }
+        chol_solve_r<NU>(L, rinv, kv);
+        chol_solve_r<NU>(L, rinv, Kc);
+      }
+      if (!boxed) {
+        if (plain_bad) failed = true;
+      } else {
+        // When no index is clamped at x0, the QP iteration has two cheap outcomes that need no
+        // projected-Newton loop:
+        //   (a) |g(x0)|_inf <= th_grad: BoxQP returns x0 itself with every index free;
+        //   (b) otherwise it takes the full Newton step to the unconstrained minimiser -Quu^-1 Qu; when
+        //       that point is strictly inside the box the step is accepted at alpha = 1 and the next
+        //       gradient test passes, again with every index free.
+        // In both, Hff^-1 = Quu^-1, so K is the plain gain above.  Everything else runs BoxQP.
+        bool interior = !any_clamped && !plain_bad && sp.boxqp_reg == 0.0;
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) {
           const double dlt = -kv[c], mrg = 1e-9 * (1.0 + fabs(dlt));
           interior = interior && (dlt > lb[c] + mrg) && (dlt < ub[c] - mrg);
         }
-        if (!any_clamped && !failed && sp.boxqp_reg == 0.0 && gnorm0 <= sp.boxqp_th_grad) {
+        if (!any_clamped && !plain_bad && sp.boxqp_reg == 0.0 && gnorm0 <= sp.boxqp_th_grad) {
           ASLR_UNROLL for (int c = 0; c < NU; ++c) kv[c] = -x0[c]; // (a)
-        } else if ((!any_clamped && interior) || (sp.debug & 4)) {
+        } else if (interior || (sp.debug & 4)) {
           // (b): kv, Kc already hold the result
         } else {
           double xq[NU];

@@ -14,7 +14,9 @@
 
 namespace aslr {
 
-template <int NJ, int DAM, bool PLANAR>
+// FDDP: the gap-contracting rollout and the dv terms of SolverFDDP are compiled in (two more 8-double prefetch
+// buffers per lane); the DDP / BoxDDP variant does not carry them.
+template <int NJ, int DAM, bool PLANAR, bool FDDP>
 __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
   constexpr int TEAM = 16, TPW = 4;
@@ -33,7 +35,7 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
   const int ai = al < ASLR_NALPHA ? al : ASLR_NALPHA - 1;
   const double alpha = 1.0 / (double)(1 << ai);
   const int feasible = TI[ASLR_TI_FEASIBLE * B + b];
-  const bool fddp = sp.solver == ASLR_SOLVER_FDDP, box = sp.solver == ASLR_SOLVER_BOXDDP;
+  const bool fddp = FDDP && sp.solver == ASLR_SOLVER_FDDP, box = sp.solver == ASLR_SOLVER_BOXDDP;
   const bool use_gaps = fddp && !(feasible || alpha == 1.0);
   const bool need_dv = fddp && !feasible;
   const DevDesc &D = *a.desc;

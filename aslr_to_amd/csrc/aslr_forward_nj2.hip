@@ -7,10 +7,12 @@ int launch_forward_nj2(const KArgs &k, int dam, const SolverDev &sd, const Model
       cblock(256), ugrid((k.B + 63) / 64, ASLR_NALPHA);
   if (dam == ASLR_DAM_SEA) {
     if (k.planar) {
-      hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_SEA, true>), grid, block, 0, st, k, sd, lim);
+      if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_SEA, true, true>), grid, block, 0, st, k, sd, lim);
+      else hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_SEA, true, false>), grid, block, 0, st, k, sd, lim);
       hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_SEA, true>), cgrid, cblock, 0, st, k, sd);
     } else {
-      hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_SEA, false>), grid, block, 0, st, k, sd, lim);
+      if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_SEA, false, true>), grid, block, 0, st, k, sd, lim);
+      else hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_SEA, false, false>), grid, block, 0, st, k, sd, lim);
       hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_SEA, false>), cgrid, cblock, 0, st, k, sd);
     }
     hipLaunchKernelGGL((sum_cost_kernel<2>), ugrid, block, 0, st, k, sd);
@@ -20,10 +22,12 @@ int launch_forward_nj2(const KArgs &k, int dam, const SolverDev &sd, const Model
   }
   if (dam == ASLR_DAM_VSA) {
     if (k.planar) {
-      hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, true>), grid, block, 0, st, k, sd, lim);
+      if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, true, true>), grid, block, 0, st, k, sd, lim);
+      else hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, true, false>), grid, block, 0, st, k, sd, lim);
       hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_VSA, true>), cgrid, cblock, 0, st, k, sd);
     } else {
-      hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, false>), grid, block, 0, st, k, sd, lim);
+      if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, false, true>), grid, block, 0, st, k, sd, lim);
+      else hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, false, false>), grid, block, 0, st, k, sd, lim);
       hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_VSA, false>), cgrid, cblock, 0, st, k, sd);
     }
     hipLaunchKernelGGL((sum_cost_kernel<2>), ugrid, block, 0, st, k, sd);

@@ -7,7 +7,8 @@ int launch_forward_nj7(const KArgs &k, int dam, const SolverDev &sd, const Model
       cblock(256), ugrid((k.B + 63) / 64, ASLR_NALPHA);
   if (dam == ASLR_DAM_SEA) {
     {
-      hipLaunchKernelGGL((rollout_kernel<7, ASLR_DAM_SEA, false>), grid, block, 0, st, k, sd, lim);
+      if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<7, ASLR_DAM_SEA, false, true>), grid, block, 0, st, k, sd, lim);
+      else hipLaunchKernelGGL((rollout_kernel<7, ASLR_DAM_SEA, false, false>), grid, block, 0, st, k, sd, lim);
       hipLaunchKernelGGL((trial_cost_kernel<7, ASLR_DAM_SEA, false>), cgrid, cblock, 0, st, k, sd);
     }
     hipLaunchKernelGGL((sum_cost_kernel<7>), ugrid, block, 0, st, k, sd);

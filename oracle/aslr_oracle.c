@@ -825,7 +825,11 @@ int aslr_cpu_calc(const aslr_problem_desc_t *d, const double *xs, const double *
 /* diagnostics (serial runs only): number of calls, projected-Newton iterations, line-search trials */
 /* thread-local: OpenMP workers keep their own (the getters report the calling thread, i.e. serial runs) */
 static __thread long long g_qp_calls, g_qp_iters, g_qp_trials, g_qp_maxed;
-static __thread long long g_qp_hist_it[16], g_qp_hist_tr[32];
+static __thread long long g_qp_hist_it[16], g_qp_hist_tr[32], g_qp_hist_c0[2][16];
+void aslr_cpu_boxqp_hist_c0(long long *o32, int reset) {
+  for (int i = 0; i < 32; ++i) o32[i] = g_qp_hist_c0[i / 16][i % 16];
+  if (reset) memset(g_qp_hist_c0, 0, sizeof g_qp_hist_c0);
+}
 void aslr_cpu_boxqp_hist(long long *it16, long long *tr32, int reset) {
   for (int i = 0; i < 16; ++i) it16[i] = g_qp_hist_it[i];
   for (int i = 0; i < 32; ++i) tr32[i] = g_qp_hist_tr[i];
@@ -845,6 +849,7 @@ int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, co
   for (int i = 0; i < n; ++i) x[i] = fmax(fmin(x[i], ub[i]), lb[i]);
   g_qp_calls++;
   long long tr0 = g_qp_trials;
+  int nc0 = 0;
   for (k = 0; k < maxiter; ++k) {
     g_qp_iters++;
     nf = nc = 0;
@@ -857,6 +862,7 @@ int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, co
       if ((x[j] == lb[j] && g[j] > 0.0) || (x[j] == ub[j] && g[j] < 0.0)) clamped_idx[nc++] = j;
       else free_idx[nf++] = j;
     }
+    if (k == 0) nc0 = nc > 0;
     double gnorm = 0.0;
     for (int i = 0; i < nf; ++i) gnorm = fmax(gnorm, fabs(g[free_idx[i]]));
     for (int i = 0; i < nf; ++i)
@@ -872,6 +878,7 @@ int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, co
       }
       *nf_o = nf; *nc_o = nc;
       g_qp_hist_it[k < 15 ? k : 15]++;
+      g_qp_hist_c0[nc0][k < 15 ? k : 15]++;
       { long long tr = g_qp_trials - tr0; g_qp_hist_tr[tr < 0 ? 0 : (tr < 31 ? tr : 31)]++; }
       return k;
     }

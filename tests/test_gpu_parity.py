@@ -179,3 +179,90 @@ def test_solve_matches_oracle(oracle, name, kw, solver):
     assert dx < 1e-6 and du < 1e-6, (dx, du)
     assert dc < 1e-4, dc
     assert (it_g == it_r)[conv].all()
+
+
+def _indefinite_sea(B, T, cost_name, weight):
+    """SEA problem with one NEGATIVE cost weight: Quu / Vxx turn indefinite, so backward passes fail
+    (Cholesky "backward_error" -> increaseRegularization -> retry without recalc) and the
+    solve ends at reg_max or keeps iterating at a raised regularisation."""
+    sc = scenarios.two_dof_sea(B=B, T=T)
+    sc["running"][0].differential.costs.costs[cost_name].weight = weight
+    return sc
+
+
+@pytest.mark.parametrize("cost_name,weight,maxiter,hits_reg_max",
+                         [("uReg", -5e-3, 12, False), ("xReg", -1e-2, 12, True), ("uReg", -1e12, 30, True)])
+def test_backward_error_recovery_and_reg_max_match_oracle(oracle, cost_name, weight, maxiter, hits_reg_max):
+    # (a cost that is unbounded below makes the iterates run away exponentially: rounding differences of 1e-13
+    #  reach O(1) after ~15 iterations on either side, so the recovery cases stop at 12 iterations)
+    sc = _indefinite_sea(6, 20, cost_name, weight)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc, maxiter=maxiter)
+    ref = oracle.solve(low, sp)
+    e = _engine(low)
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=3)
+    _sync()
+    st_g, st_r = _np(e.traj_i(_abi.TI_STATUS)), ref["traj_i"][_abi.TI_STATUS]
+    assert ((st_r & _abi.ST_BACKWARD_ERR) != 0).all()          # the path under test was taken
+    assert ((st_r & _abi.ST_REG_MAX) != 0).any() == hits_reg_max
+    np.testing.assert_array_equal(st_g, st_r)
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER])
+    np.testing.assert_allclose(_np(e.traj_f(_abi.TF_XREG)), ref["traj_f"][_abi.TF_XREG], rtol=0)
+    # run-away iterates (the negative weight makes the cost unbounded below) amplify rounding differences
+    # without bound: values are compared per trajectory relative to its size, on those that stayed below 1e6;
+    # status, iteration count and regularisation above are compared on all of them
+    mag = np.maximum(np.abs(ref["xs"]).max(axis=(0, 2)), np.abs(ref["us"]).max(axis=(0, 2)))
+    tame = mag < 1e6
+    assert tame.any()
+    scale = np.maximum(1.0, mag)[tame]
+    assert (np.abs(_np(e.region(_abi.R_XS)) - ref["xs"])[:, tame].max(axis=(0, 2)) < 1e-6 * scale).all()
+    assert (np.abs(_np(e.region(_abi.R_US)) - ref["us"])[:, tame].max(axis=(0, 2)) < 1e-6 * scale).all()
+
+
+def test_forward_error_is_skipped_like_crocoddyl(oracle):
+    """A rollout that overflows (NaN / Inf / >= 1e30) makes that step length a "forward_error": it is skipped and
+    the next alpha is tried.  Huge feed-forward terms provoke it."""
+    import torch
+    sc = scenarios.two_dof_sea(B=4, T=40)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc)
+    e = _engine(low)
+    xs = np.zeros((low.T + 1, low.B, low.nx))
+    us = np.zeros((low.T, low.B, low.nu))
+    K = np.zeros((low.T, low.B, low.nu, low.nx))
+    k = np.full((low.T, low.B, low.nu), -1e200)  # u = us - alpha k: overflows to inf in a few steps for large alpha
+    e.region(_abi.R_XS).copy_(torch.as_tensor(xs)); e.region(_abi.R_US).copy_(torch.as_tensor(us))
+    e.region(_abi.R_KGAIN).copy_(torch.as_tensor(K)); e.region(_abi.R_KFF).copy_(torch.as_tensor(k))
+    e.region(_abi.R_TRAJ_I)[_abi.TI_FEASIBLE].fill_(1)
+    e.forward_pass(sp)
+    _sync()
+    for a in range(_abi.NALPHA):
+        _, _, cost_try, fail = oracle.forward_pass(low, sp, 0.5 ** a, xs, us, K, k)
+        got = _np(e.traj_f(_abi.TF_COST_TRY0 + a))
+        np.testing.assert_array_equal(np.isnan(got), fail != 0)
+        assert fail.all()
+
+
+def test_edge_sizes_single_knot_single_trajectory(oracle):
+    for B, T in ((1, 1), (3, 2), (65, 1)):
+        sc = scenarios.two_dof_vsa_boxddp(B=B, T=T)
+        low = scenarios.lower(sc)
+        sp = scenarios.solver_params(sc, maxiter=15)
+        ref = oracle.solve(low, sp)
+        e = _engine(low)
+        e.set_candidate(None, None)
+        e.solve(sp, poll_every=1)
+        _sync()
+        assert np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max() < 1e-6
+        assert np.abs(_np(e.region(_abi.R_US)) - ref["us"]).max() < 1e-6
+        np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER])
+        np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)), ref["traj_i"][_abi.TI_STATUS])
+    # maxiter = 0 leaves the candidate untouched
+    sc = scenarios.two_dof_sea(B=2, T=5)
+    e = _engine(scenarios.lower(sc))
+    xs0 = np.random.default_rng(0).normal(size=(2, 6, 8))
+    e.set_candidate(xs0, None)
+    e.solve(scenarios.solver_params(sc, maxiter=0))
+    _sync()
+    np.testing.assert_array_equal(_np(e.xs), xs0)
