@@ -196,10 +196,10 @@ ModelLimits make_limits(const aslr_problem *p) {
 }
 
 int backward_hs(const aslr_problem *p) {
-  // rows of each column split over HS lanes: wider teams when the batch cannot fill the chip
+  // 0: each size picks its default decomposition; ASLR_BWD_HS forces the register-column kernel with that
+  // many lanes per column (tests and comparisons)
   const char *e = getenv("ASLR_BWD_HS");
-  if (e) return atoi(e);
-  return p->desc.B <= 8192 ? 2 : 1;
+  return e ? atoi(e) : 0;
 }
 
 int launch_backward(aslr_problem *p, const SolverDev &sd, hipStream_t st, bool all_feasible = false) {

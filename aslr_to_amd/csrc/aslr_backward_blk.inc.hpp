@@ -1,0 +1,414 @@
+// aslr_backward_blk.inc.hpp -- Riccati backward pass for the larger state (nx = 28, 7-DoF SEA):
+// ONE 128-THREAD BLOCK PER TRAJECTORY, every operand of the recursion resident in LDS.
+//
+// SolverDDP / SolverFDDP backwardPass + computeGains; same formulas, same summation
+// order per entry as backward_kernel (aslr_backward.inc.hpp).  That kernel keeps a column of every matrix in
+// registers, which at nx = 28 needs ~2x the register file and spills to scratch; here:
+//
+//   * thread (rr, g) = (tid >> 3, tid & 7) owns rows rr and rr + 16, columns 4g..4g+3 of every nx x nx product
+//     (2 x 4 outputs per thread: 16 FMAs per 6 LDS reads); the left operands are read as pairs along the
+//     contraction index, the right operand as the 4 contiguous doubles of a row (ds_read_b128, conflict-free);
+//   * 128 threads = 2 waves per trajectory: the C5 shard (512 trajectories per GPU) is then 1024 waves, one per
+//     SIMD, each with the whole register file -- nothing spills;
+//   * products: C = P Fx (stored transposed: A = Fx^T P) and P Fu in one sweep over the contraction index,
+//     then Qxx = Lxx + A Fx, and [Qux | Quu] = [Lxu^T | Luu] + (Fu^T P) [Fx | Fu] with one entry per thread;
+//   * the nu x nu Cholesky, the nx + 1 triangular solves (one column of K per lane), Quu k, Vx and the
+//     expected-improvement terms run in wave 0 while the other waves wait at the barrier;
+//   * Vxx = Qxx - Qux^T K, its symmetrisation and the NaN / 1e30 test are again one row x 4 columns per thread;
+//   * the next knot's record (16 KB) is prefetched into registers (8 x 16 B per thread) during the knot.
+//
+// Box constraints are not handled here: a SolverBoxDDP problem of this size takes backward_kernel.
+#pragma once
+#include "aslr_backward.inc.hpp"
+
+namespace aslr {
+
+template <int NX, int NU>
+struct BwdBlk {
+  static_assert(NX % 4 == 0 && NX > 16 && NX <= 32 && NU <= 8, "thread map: (16 x 2) rows x 8 groups of 4 columns");
+  static constexpr int NT = 128;
+  static constexpr int NG = NX / 4;
+  static constexpr int REC = rec_len_c(NX, NU);
+  static constexpr int NPRE = (REC / 2 + NT - 1) / NT; // double2 prefetch registers per thread
+  static constexpr int oFx = 0, oFu = oFx + NX * NX, oLxx = oFu + NX * NU, oLxu = oLxx + NX * NX,
+                       oLuu = oLxu + NX * NU, oLx = oLuu + NU * NU, oLu = oLx + NX;
+  static constexpr int even(int v) { return (v + 1) / 2 * 2; }
+  // LDS arrays (doubles); every base is even (16-byte aligned)
+  static constexpr int sRec = 0, sPT = sRec + even(REC), sA = sPT + NX * NX, sB = sA + NX * NX,
+                       sQux = sB + even(NU * NX), sQuxT = sQux + even(NU * NX), sK = sQuxT + NX * 8,
+                       sQuu = sK + even(NU * NX), sQu = sQuu + 64, sQx = sQu + 8, sVx = sQx + 32, sF = sVx + 32,
+                       sRed = sF + 32, sCost = sRed + 64, sFlag = sCost + NT, sEnd = sFlag + 2;
+  static constexpr int LDS = even(sEnd);
+};
+
+template <int NX, int NU, bool GAPS>
+__global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp) {
+  using C = BwdBlk<NX, NU>;
+  constexpr int REC = C::REC, NG = C::NG, NT = C::NT;
+  __shared__ double sm[C::LDS];
+  double *rec = sm + C::sRec, *PT = sm + C::sPT, *AL = sm + C::sA, *BL = sm + C::sB, *QuxL = sm + C::sQux,
+         *QuxT = sm + C::sQuxT, *KL = sm + C::sK, *QuuL = sm + C::sQuu, *QuL = sm + C::sQu, *QxL = sm + C::sQx,
+         *VxL = sm + C::sVx, *FL = sm + C::sF, *RedL = sm + C::sRed, *CostL = sm + C::sCost;
+  int *FlagL = reinterpret_cast<int *>(sm + C::sFlag);
+
+  const int tid = threadIdx.x, rr = tid >> 3, g = tid & 7;
+  const int gc = g < NG ? g : NG - 1, gu = g < NU ? g : NU - 1;
+  const int row[2] = {rr, rr + 16 < NX ? rr + 16 : NX - 1};               // rows of this thread (second clamped)
+  const bool cell[2] = {g < NG, g < NG && rr + 16 < NX};                  // it owns entries (row[h], 4g..4g+3)
+  const bool wave0 = tid < 64;
+  const int B = a.B, T = a.T, b = blockIdx.x;
+  int32_t *TI = a.traj_i;
+  double *TF = a.traj_f;
+
+  // ---- prologue: solver-state bookkeeping that Crocoddyl does inside calcDiff ----
+  int done = 0, feasible = TI[ASLR_TI_FEASIBLE * B + b], status = TI[ASLR_TI_STATUS * B + b];
+  if (!sp.standalone) {
+    done = TI[ASLR_TI_DONE * B + b];
+    const int recalc = TI[ASLR_TI_RECALC * B + b];
+    if (!done && recalc) {
+      if (!feasible) feasible = TI[ASLR_TI_GAPFLAG * B + b] ? 0 : 1;
+      // cost_ = sum of node costs, in node order: loads spread over the block, adds by one thread
+      double csum = 0.0;
+      for (int t0 = 0; t0 <= T; t0 += NT) {
+        __syncthreads();
+        if (t0 + tid <= T) CostL[tid] = a.cost[(size_t)(t0 + tid) * B + b];
+        __syncthreads();
+        if (tid == 0) {
+          const int n = T + 1 - t0 < NT ? T + 1 - t0 : NT;
+          for (int q = 0; q < n; ++q) csum += CostL[q];
+        }
+      }
+      if (tid == 0) TF[ASLR_TF_COST * B + b] = csum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      TI[ASLR_TI_FEASIBLE * B + b] = feasible;
+      TI[ASLR_TI_ACCEPTED * B + b] = -1;
+      TI[ASLR_TI_GAPFLAG * B + b] = 0;
+    }
+  }
+  if (done) return;
+  bool need = true;
+  double xreg = TF[ASLR_TF_XREG * B + b];
+  const bool fddp = GAPS && sp.solver == ASLR_SOLVER_FDDP;
+  const bool gaps_on = GAPS && !feasible;
+
+  // pass-2b tasks: entries e of [Qux (nu x nx) | Quu (nu x nu)], e = tid and tid + NT (compile-time strides on
+  // each path: a per-thread stride makes the compiler keep one LDS address per contraction step)
+  constexpr int NQX = NU * NX, NQ = NQX + NU * NU;
+  static_assert(NT < NQX && NQ <= 2 * NT, "two tasks per thread, the first always in Qux");
+  const int e1 = tid + NT;
+  const bool e1x = e1 < NQX, e1u = !e1x && e1 < NQ;
+  const int k2a = tid / NX, c2a = tid % NX;
+  const int k2b = e1x ? e1 / NX : 0, c2b = e1x ? e1 % NX : 0;
+  const int k3 = e1u ? (e1 - NQX) / NU : 0, c3 = e1u ? (e1 - NQX) % NU : 0;
+
+  double d1 = 0.0, d2 = 0.0, stop = 0.0, dgf = 0.0, dqf = 0.0;
+  while (need) {
+    bool failed = false;
+    d1 = d2 = stop = dgf = dqf = 0.0;
+    const double xr = isnan(xreg) ? 0.0 : xreg;
+    double Vx_own = 0.0; // threads tid < NX: entry tid of Vx
+    // ---- terminal node: Vxx = Lxx (+xreg), Vx = Lx (+ Vxx f) ----
+    {
+      const double *rT = a.deriv + ((size_t)T * B + b) * REC;
+      __syncthreads();
+      // PT[c][l] = P(l, c): the record's Lxx is taken as stored (it is symmetric up to rounding only)
+      for (int e = tid; e < NX * NX; e += NT) {
+        const int l = e / NX, c = e % NX;
+        PT[c * NX + l] = rT[C::oLxx + e] + (l == c ? xr : 0.0);
+      }
+      if (tid < NX) Vx_own = rT[C::oLx + tid];
+      if (gaps_on && tid < NX) FL[tid] = a.gaps[((size_t)T * B + b) * NX + tid];
+      __syncthreads();
+      if (gaps_on && tid < NX) {
+        double vf = 0.0;
+        for (int q = 0; q < NX; ++q) vf += PT[tid * NX + q] * FL[q];
+        Vx_own += vf;
+        if (fddp) {
+          dgf -= Vx_own * FL[tid];
+          dqf += FL[tid] * vf;
+          a.vxxf[((size_t)T * B + b) * NX + tid] = vf;
+        }
+      }
+      if (sp.store_v) {
+        if (tid < NX) a.vx[((size_t)T * B + b) * NX + tid] = Vx_own;
+        double *o = a.vxx + ((size_t)T * B + b) * NX * NX;
+        for (int e = tid; e < NX * NX; e += NT) o[e] = PT[(e % NX) * NX + e / NX];
+      }
+      if (tid < NX) VxL[tid] = Vx_own;
+    }
+    // ---- prefetch of knot T-1 ----
+    double prx[C::NPRE], pry[C::NPRE], pre_f = 0.0;
+#define ASLR_BLK_PREFETCH(tt)                                                                          \
+    do {                                                                                               \
+      const size_t tbp = (size_t)(tt) * B + b;                                                         \
+      typedef double nt_double2 __attribute__((ext_vector_type(2)));                                   \
+      const nt_double2 *src = reinterpret_cast<const nt_double2 *>(a.deriv + tbp * REC);               \
+      ASLR_UNROLL for (int q = 0; q < C::NPRE; ++q) {                                                  \
+        const int idx = tid + NT * q;                                                                  \
+        if (C::NPRE * NT == REC / 2 || idx < REC / 2) { const nt_double2 v2 = __builtin_nontemporal_load(src + idx); prx[q] = v2.x; pry[q] = v2.y; } \
+      }                                                                                                \
+      if (gaps_on && tid < NX) pre_f = a.gaps[tbp * NX + tid];                                         \
+    } while (0)
+    ASLR_BLK_PREFETCH(T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+      const size_t tb = (size_t)t * B + b;
+      __syncthreads(); // every reader of the previous knot's record is done; PT / VxL of this knot are written
+      {
+        double2 *dst = reinterpret_cast<double2 *>(rec);
+        ASLR_UNROLL for (int q = 0; q < C::NPRE; ++q) {
+          const int idx = tid + NT * q;
+          if (C::NPRE * NT == REC / 2 || idx < REC / 2) { double2 v2; v2.x = prx[q]; v2.y = pry[q]; dst[idx] = v2; }
+        }
+        if (gaps_on && tid < NX) FL[tid] = pre_f;
+      }
+      __syncthreads();
+      if (t > 0) ASLR_BLK_PREFETCH(t - 1);
+
+      // ---- pass 1: C(r, 4g..) = sum_l P(r,l) Fx(l, 4g..)  [= A(4g.., r)],  (P Fu)(r, g) [= B(g, r)] ----
+      {
+        double c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, bu[2] = {0.0, 0.0};
+        const double2 *prow0 = reinterpret_cast<const double2 *>(PT + row[0] * NX);
+        const double2 *prow1 = reinterpret_cast<const double2 *>(PT + row[1] * NX);
+        _Pragma("unroll 2") for (int l = 0; l < NX; l += 2) {
+          const double2 p[2] = {prow0[l / 2], prow1[l / 2]};
+          const double2 *f0 = reinterpret_cast<const double2 *>(rec + C::oFx + l * NX + 4 * gc);
+          const double2 *f1 = reinterpret_cast<const double2 *>(rec + C::oFx + (l + 1) * NX + 4 * gc);
+          const double2 f0a = f0[0], f0b = f0[1], f1a = f1[0], f1b = f1[1];
+          const double u0 = rec[C::oFu + l * NU + gu], u1 = rec[C::oFu + (l + 1) * NU + gu];
+          ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+            c[h][0] += p[h].x * f0a.x; c[h][1] += p[h].x * f0a.y; c[h][2] += p[h].x * f0b.x; c[h][3] += p[h].x * f0b.y;
+            bu[h] += p[h].x * u0;
+            c[h][0] += p[h].y * f1a.x; c[h][1] += p[h].y * f1a.y; c[h][2] += p[h].y * f1b.x; c[h][3] += p[h].y * f1b.y;
+            bu[h] += p[h].y * u1;
+          }
+        }
+        ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+          if (cell[h]) { ASLR_UNROLL for (int q = 0; q < 4; ++q) AL[(4 * g + q) * NX + row[h]] = c[h][q]; }
+          if (g < NU && (h == 0 || rr + 16 < NX)) BL[g * NX + row[h]] = bu[h];
+        }
+      }
+      if (tid < NX) { // Qx = Lx + Fx^T Vx, Qu = Lu + Fu^T Vx (wave 0)
+        double s = 0.0;
+        ASLR_UNROLL for (int l = 0; l < NX; ++l) s += rec[C::oFx + l * NX + tid] * VxL[l];
+        QxL[tid] = rec[C::oLx + tid] + s;
+      } else if (tid < NX + NU) {
+        double s = 0.0;
+        ASLR_UNROLL for (int l = 0; l < NX; ++l) s += rec[C::oFu + l * NU + (tid - NX)] * VxL[l];
+        QuL[tid - NX] = rec[C::oLu + (tid - NX)] + s;
+      }
+      __syncthreads();
+      // ---- pass 2a: Qxx(r, 4g..) = Lxx + sum_l A(r,l) Fx(l, 4g..) ----
+      double qxx[2][4];
+      {
+        double c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        const double2 *arow0 = reinterpret_cast<const double2 *>(AL + row[0] * NX);
+        const double2 *arow1 = reinterpret_cast<const double2 *>(AL + row[1] * NX);
+        _Pragma("unroll 2") for (int l = 0; l < NX; l += 2) {
+          const double2 p[2] = {arow0[l / 2], arow1[l / 2]};
+          const double2 *f0 = reinterpret_cast<const double2 *>(rec + C::oFx + l * NX + 4 * gc);
+          const double2 *f1 = reinterpret_cast<const double2 *>(rec + C::oFx + (l + 1) * NX + 4 * gc);
+          const double2 f0a = f0[0], f0b = f0[1], f1a = f1[0], f1b = f1[1];
+          ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+            c[h][0] += p[h].x * f0a.x; c[h][1] += p[h].x * f0a.y; c[h][2] += p[h].x * f0b.x; c[h][3] += p[h].x * f0b.y;
+            c[h][0] += p[h].y * f1a.x; c[h][1] += p[h].y * f1a.y; c[h][2] += p[h].y * f1b.x; c[h][3] += p[h].y * f1b.y;
+          }
+        }
+        ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+          const double2 *lx = reinterpret_cast<const double2 *>(rec + C::oLxx + row[h] * NX + 4 * gc);
+          const double2 la = lx[0], lb2 = lx[1];
+          qxx[h][0] = la.x + c[h][0]; qxx[h][1] = la.y + c[h][1]; qxx[h][2] = lb2.x + c[h][2]; qxx[h][3] = lb2.y + c[h][3];
+        }
+      }
+      // ---- pass 2b: entries tid and tid + NT of [Qux | Quu] ----
+      {
+        double s = 0.0;
+        const double2 *brow = reinterpret_cast<const double2 *>(BL + k2a * NX);
+        _Pragma("unroll 2") for (int l = 0; l < NX; l += 2) {
+          const double2 p = brow[l / 2];
+          s += p.x * rec[C::oFx + l * NX + c2a];
+          s += p.y * rec[C::oFx + (l + 1) * NX + c2a];
+        }
+        const double v = rec[C::oLxu + c2a * NU + k2a] + s;
+        QuxL[k2a * NX + c2a] = v;
+        QuxT[c2a * 8 + k2a] = v;
+      }
+      if (e1x) {
+        double s = 0.0;
+        const double2 *brow = reinterpret_cast<const double2 *>(BL + k2b * NX);
+        _Pragma("unroll 2") for (int l = 0; l < NX; l += 2) {
+          const double2 p = brow[l / 2];
+          s += p.x * rec[C::oFx + l * NX + c2b];
+          s += p.y * rec[C::oFx + (l + 1) * NX + c2b];
+        }
+        const double v = rec[C::oLxu + c2b * NU + k2b] + s;
+        QuxL[k2b * NX + c2b] = v;
+        QuxT[c2b * 8 + k2b] = v;
+      } else if (e1u) {
+        double s = 0.0;
+        const double2 *brow = reinterpret_cast<const double2 *>(BL + k3 * NX);
+        _Pragma("unroll 2") for (int l = 0; l < NX; l += 2) {
+          const double2 p = brow[l / 2];
+          s += p.x * rec[C::oFu + l * NU + c3];
+          s += p.y * rec[C::oFu + (l + 1) * NU + c3];
+        }
+        QuuL[k3 * NU + c3] = rec[C::oLuu + k3 * NU + c3] + s + (k3 == c3 ? xr : 0.0);
+      }
+      __syncthreads();
+      // ---- gains (wave 0): K = Quu^-1 Qux (one column per lane), k = Quu^-1 Qu, Quu k, Vx, d1, d2, stop ----
+      if (wave0) {
+        double L[NU][NU], rinv[NU], qu[NU], kv[NU], Kc[NU], Quuk[NU];
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) // (chol_rs reads the lower triangle only)
+          ASLR_UNROLL for (int e = 0; e < NU; ++e) L[c][e] = e <= c ? QuuL[c * NU + e] : 0.0;
+        const bool bad = chol_rs<NU>(L, rinv);
+        const int col = tid < NX ? tid : NX - 1;
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) { qu[c] = QuL[c]; kv[c] = qu[c]; Kc[c] = QuxL[c * NX + col]; }
+        chol_solve_r<NU>(L, rinv, kv);
+        chol_solve_r<NU>(L, rinv, Kc);
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+          double s = 0.0;
+          ASLR_UNROLL for (int e = 0; e < NU; ++e) s += QuuL[c * NU + e] * kv[e];
+          Quuk[c] = s;
+        }
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) { d1 += qu[c] * kv[c]; d2 -= kv[c] * Quuk[c]; stop += qu[c] * qu[c]; }
+        {
+          double s = 0.0, s2 = 0.0;
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) { s += Kc[c] * Quuk[c]; s2 += Kc[c] * qu[c]; }
+          Vx_own = QxL[col] + s - 2.0 * s2;
+        }
+        if (tid < NX) { ASLR_UNROLL for (int c = 0; c < NU; ++c) KL[c * NX + tid] = Kc[c]; }
+        if (tid == 0) {
+          FlagL[0] = bad ? 1 : 0;
+          if (!bad) {
+            ASLR_UNROLL for (int c = 0; c < NU; ++c) { a.kff[tb * NU + c] = kv[c]; a.qu[tb * NU + c] = qu[c]; }
+          }
+        }
+      }
+      __syncthreads();
+      if (FlagL[0]) { failed = true; break; } // block-uniform
+      // ---- Vxx (unsymmetrised, state regularisation on the diagonal), K to HBM ----
+      {
+        double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, k8[2][8];
+        ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+          const double2 *qt = reinterpret_cast<const double2 *>(QuxT + row[h] * 8);
+          ASLR_UNROLL for (int c = 0; c < 8; c += 2) { const double2 v = qt[c / 2]; k8[h][c] = v.x; k8[h][c + 1] = v.y; }
+        }
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+          const double2 *kr = reinterpret_cast<const double2 *>(KL + c * NX + 4 * gc);
+          const double2 ka = kr[0], kb = kr[1];
+          ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+            acc[h][0] += k8[h][c] * ka.x; acc[h][1] += k8[h][c] * ka.y; acc[h][2] += k8[h][c] * kb.x; acc[h][3] += k8[h][c] * kb.y;
+          }
+        }
+        ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+          if (cell[h]) {
+            double2 *vo = reinterpret_cast<double2 *>(AL + row[h] * NX + 4 * g);
+            double2 va, vb;
+            va.x = (qxx[h][0] - acc[h][0]) + (row[h] == 4 * g + 0 ? xr : 0.0);
+            va.y = (qxx[h][1] - acc[h][1]) + (row[h] == 4 * g + 1 ? xr : 0.0);
+            vb.x = (qxx[h][2] - acc[h][2]) + (row[h] == 4 * g + 2 ? xr : 0.0);
+            vb.y = (qxx[h][3] - acc[h][3]) + (row[h] == 4 * g + 3 ? xr : 0.0);
+            vo[0] = va; vo[1] = vb;
+          }
+        }
+        a.kgain[tb * NU * NX + tid] = KL[tid];
+        if (tid + NT < NU * NX) a.kgain[tb * NU * NX + tid + NT] = KL[tid + NT];
+      }
+      __syncthreads();
+      // ---- symmetrise into PT, NaN / Inf / >= 1e30 test ("backward_error") ----
+      bool bad = false;
+      double2 pa[2], pb[2];
+      ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+        const int rw = row[h];
+        const double2 *vr = reinterpret_cast<const double2 *>(AL + rw * NX + 4 * gc);
+        const double2 va = vr[0], vb = vr[1];
+        pa[h].x = 0.5 * (va.x + AL[(4 * gc + 0) * NX + rw]); pa[h].y = 0.5 * (va.y + AL[(4 * gc + 1) * NX + rw]);
+        pb[h].x = 0.5 * (vb.x + AL[(4 * gc + 2) * NX + rw]); pb[h].y = 0.5 * (vb.y + AL[(4 * gc + 3) * NX + rw]);
+        if (cell[h]) {
+          double2 *po = reinterpret_cast<double2 *>(PT + rw * NX + 4 * g);
+          po[0] = pa[h]; po[1] = pb[h];
+          bad = bad || is_bad(fabs(pa[h].x) + fabs(pa[h].y) + fabs(pb[h].x) + fabs(pb[h].y));
+        }
+      }
+      if (gaps_on) {
+        __syncthreads();
+        if (tid < NX) {
+          double vf = 0.0;
+          for (int q = 0; q < NX; ++q) vf += PT[tid * NX + q] * FL[q];
+          Vx_own += vf;
+          if (fddp) {
+            dgf -= Vx_own * FL[tid];
+            dqf += FL[tid] * vf;
+            a.vxxf[tb * NX + tid] = vf;
+          }
+        }
+      }
+      if (tid < NX) bad = bad || is_bad(fabs(Vx_own));
+      if (__syncthreads_or(bad ? 1 : 0)) { failed = true; break; }
+      if (sp.store_v) {
+        if (tid < NX) a.vx[tb * NX + tid] = Vx_own;
+        ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+          if (cell[h]) {
+            double2 *o = reinterpret_cast<double2 *>(a.vxx + tb * NX * NX + row[h] * NX + 4 * g);
+            o[0] = pa[h]; o[1] = pb[h];
+          }
+        }
+      }
+      if (tid < NX) VxL[tid] = Vx_own;
+    }
+#undef ASLR_BLK_PREFETCH
+    // ---- end of sweep: publish or regularise and retry ----
+    if (!failed) {
+      if (fddp) { // per-column gap terms summed in column order by one thread
+        __syncthreads();
+        if (tid < NX) { RedL[tid] = dgf; RedL[32 + tid] = dqf; }
+        __syncthreads();
+        if (tid == 0) {
+          dgf = 0.0; dqf = 0.0;
+          for (int q = 0; q < NX; ++q) { dgf += RedL[q]; dqf += RedL[32 + q]; }
+        }
+      }
+      if (tid == 0) {
+        TF[ASLR_TF_STOP * B + b] = stop;
+        if (fddp) {
+          TF[ASLR_TF_DG * B + b] = d1 + dgf;
+          TF[ASLR_TF_DQ * B + b] = d2 + dqf;
+        }
+        TF[ASLR_TF_D1 * B + b] = d1;
+        TF[ASLR_TF_D2 * B + b] = d2;
+        TF[ASLR_TF_XREG * B + b] = xreg;
+        TI[ASLR_TI_STATUS * B + b] = status;
+      }
+      need = false;
+    } else {
+      status |= ASLR_ST_BACKWARD_ERR;
+      if (sp.standalone) {
+        if (tid == 0) TI[ASLR_TI_STATUS * B + b] = status;
+        need = false;
+      } else {
+        xreg *= sp.reg_incfactor;
+        if (xreg > sp.reg_max) xreg = sp.reg_max;
+        if (xreg == sp.reg_max) {
+          status |= ASLR_ST_REG_MAX;
+          if (tid == 0) {
+            TF[ASLR_TF_XREG * B + b] = xreg;
+            TI[ASLR_TI_STATUS * B + b] = status;
+            TI[ASLR_TI_DONE * B + b] = 1;
+          }
+          need = false;
+        }
+      }
+    }
+  }
+}
+
+template <int NX, int NU>
+int launch_backward_blk(const KArgs &k, const SolverDev &sd, bool all_feasible, hipStream_t st) {
+  if (all_feasible) hipLaunchKernelGGL((backward_blk_kernel<NX, NU, false>), dim3(k.B), dim3(BwdBlk<NX, NU>::NT), 0, st, k, sd);
+  else hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true>), dim3(k.B), dim3(BwdBlk<NX, NU>::NT), 0, st, k, sd);
+  HIP_TRY(hipGetLastError());
+  return ASLR_OK;
+}
+
+} // namespace aslr

@@ -1,9 +1,15 @@
 // backward pass instantiated for nx = 28 (7-DoF SEA, nu = 7)
-#include "aslr_backward.inc.hpp"
+#include "aslr_backward_blk.inc.hpp"
 
 namespace aslr {
+// hs: 0 = default (block-per-trajectory LDS kernel; the register-column kernel for SolverBoxDDP),
+//     1 / 2 = force the register-column kernel with that many lanes per column (tests, comparisons)
 int launch_backward_nx28(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st) {
-  if (nu == 7) return hs == 2 ? launch_backward_t<28, 7, 2>(k, sd, lim, all_feasible, st) : launch_backward_t<28, 7, 1>(k, sd, lim, all_feasible, st);
+  if (nu == 7) {
+    if (hs == 0 && sd.solver != ASLR_SOLVER_BOXDDP) return launch_backward_blk<28, 7>(k, sd, all_feasible, st);
+    if (hs == 0) hs = k.B <= 8192 ? 2 : 1;
+    return hs == 2 ? launch_backward_t<28, 7, 2>(k, sd, lim, all_feasible, st) : launch_backward_t<28, 7, 1>(k, sd, lim, all_feasible, st);
+  }
   snprintf(err_buf(), kErrLen, "backward: unsupported (nx=28, nu=%d)", nu);
   return ASLR_E_INVALID;
 }

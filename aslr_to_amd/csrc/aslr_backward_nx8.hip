@@ -3,6 +3,7 @@
 
 namespace aslr {
 int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st) {
+  if (hs == 0) hs = k.B <= 8192 ? 2 : 1; // wider teams when the batch cannot fill the chip
   if (nu == 2) return hs == 2 ? launch_backward_t<8, 2, 2>(k, sd, lim, all_feasible, st) : launch_backward_t<8, 2, 1>(k, sd, lim, all_feasible, st);
   if (nu == 4) {
     const char *e = getenv("ASLR_BWD_TPW");

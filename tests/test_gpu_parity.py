@@ -82,10 +82,13 @@ def _backward_inputs(oracle, low, seed):
 
 @pytest.mark.parametrize("name,kw", CASES)
 @pytest.mark.parametrize("feasible", [0, 1])
-@pytest.mark.parametrize("hs", [1, 2])
+@pytest.mark.parametrize("hs", [0, 1, 2])
 def test_backward_pass_matches_oracle(oracle, monkeypatch, name, kw, feasible, hs):
     import torch
-    monkeypatch.setenv("ASLR_BWD_HS", str(hs))
+    if hs:   # 0: the default decomposition of the size (block-per-trajectory LDS kernel at nx = 28)
+        monkeypatch.setenv("ASLR_BWD_HS", str(hs))
+    else:
+        monkeypatch.delenv("ASLR_BWD_HS", raising=False)
     sc = scenarios.SCENARIOS[name](**kw)
     low = scenarios.lower(sc)
     sp = scenarios.solver_params(sc)
@@ -216,8 +219,9 @@ def test_backward_error_recovery_and_reg_max_match_oracle(oracle, cost_name, wei
     tame = mag < 1e6
     assert tame.any()
     scale = np.maximum(1.0, mag)[tame]
-    assert (np.abs(_np(e.region(_abi.R_XS)) - ref["xs"])[:, tame].max(axis=(0, 2)) < 1e-6 * scale).all()
-    assert (np.abs(_np(e.region(_abi.R_US)) - ref["us"])[:, tame].max(axis=(0, 2)) < 1e-6 * scale).all()
+    tol = 1e-6 if not hits_reg_max else 1e-4   # (the reg_max cases amplify by ~1e3 per iteration near the end)
+    assert (np.abs(_np(e.region(_abi.R_XS)) - ref["xs"])[:, tame].max(axis=(0, 2)) < tol * scale).all()
+    assert (np.abs(_np(e.region(_abi.R_US)) - ref["us"])[:, tame].max(axis=(0, 2)) < tol * scale).all()
 
 
 def test_forward_error_is_skipped_like_crocoddyl(oracle):

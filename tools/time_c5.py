@@ -1,0 +1,19 @@
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aslr_to_amd import scenarios, _abi as A
+from aslr_to_amd.engine import Engine
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+sc = scenarios.talos_arm_sea(B=B, T=150)
+low = scenarios.lower(sc)
+e = Engine(low)
+e.set_candidate(None, None)
+def ev(): return torch.cuda.Event(enable_timing=True)
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize(); a, b = ev(), ev(); a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / n * 1e3
+sp = scenarios.solver_params(sc, solver="SolverDDP", fixed_iterations=1)
+for i in range(5): e.iterate(sp, i == 0)
+torch.cuda.synchronize()
+print("B=%d 7-DoF SEA DDP T=150: iterate %.1f us, backward %.1f us, forward %.1f us, calc_diff %.1f us, calc %.1f us" % (
+    B, timeit(lambda: e.iterate(sp, False)), timeit(lambda: e.backward_pass(sp)), timeit(lambda: e.forward_pass(sp)), timeit(e.calc_diff), timeit(e.calc)))
