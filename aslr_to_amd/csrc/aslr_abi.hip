@@ -103,6 +103,7 @@ void carve(const aslr_problem_desc_t *d, int nx, int nu, aslr_region_t *r, int64
   sizes[ASLR_R_DESC] = sizeof(DevDesc);
   sizes[ASLR_R_NODE_MODEL] = T1 * sizeof(int32_t);
   sizes[ASLR_R_COST_TRY] = (int64_t)ASLR_NALPHA * T1 * B * D;
+  sizes[ASLR_R_DYN] = T1 * B * dyn_len_c(nx / 4) * D;
   int64_t off = 0;
   for (int i = 0; i < ASLR_R_COUNT; ++i) {
     r[i].offset = off;
@@ -344,6 +345,7 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   k.vx = (double *)reg(ASLR_R_VX); k.vxx = (double *)reg(ASLR_R_VXX); k.xs_try = (double *)reg(ASLR_R_XS_TRY);
   k.us_try = (double *)reg(ASLR_R_US_TRY); k.vxxf = (double *)reg(ASLR_R_VXXF);
   k.cost_try = (double *)reg(ASLR_R_COST_TRY);
+  k.dyn = (double *)reg(ASLR_R_DYN);
   k.traj_f = (double *)reg(ASLR_R_TRAJ_F); k.traj_i = (int32_t *)reg(ASLR_R_TRAJ_I);
   k.B = desc->B; k.T = desc->T;
   k.planar = planar_ok;
@@ -453,6 +455,10 @@ int aslr_count_active(aslr_problem_t *p, void *stream, int32_t *active) {
 
 int aslr_solve(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t poll_every, void *stream, int32_t *iters_done) {
   if (!p || !sp) return ASLR_E_INVALID;
+  if (sp->maxiter <= 0) { // nothing to iterate: the candidate stays as set (no accepted trial to commit)
+    if (iters_done) *iters_done = 0;
+    return ASLR_OK;
+  }
   int it = 0;
   for (; it < sp->maxiter; ++it) {
     int rc = aslr_iterate(p, sp, it == 0, stream);

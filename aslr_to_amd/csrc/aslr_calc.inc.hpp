@@ -15,7 +15,8 @@ constexpr int kChunk = 16;            // doubles per knot per LDS flush (one 128
 constexpr int kLdsStride = kChunk + 1; // odd stride: conflict-free ds_write_b64 across lanes
 
 
-template <int NJ, int DAM, bool DIFF, bool PLANAR>
+// PRE: the rigid-body part of the knot was computed by dyn_team_kernel (aslr_calc_team.inc.hpp) into DYN
+template <int NJ, int DAM, bool DIFF, bool PLANAR, bool PRE = false>
 __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int mode, double th_gaptol) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
   using RL = RecLayout<NJ, NU>;
@@ -76,7 +77,9 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
     const typename CH::Consts cc(D);
     ModelRegs<NJ, NU> mr;
     mr.load(dm);
-    knot_eval<NJ, DAM, DIFF ? kEvalDiff : (kEvalDyn | kEvalCost), CH>(cc, mr, dm, fref, x, t < T ? u : nullptr, xnext, cost, DIFF ? &kd : nullptr);
+    knot_eval<NJ, DAM, (DIFF ? kEvalDiff : (kEvalDyn | kEvalCost)) | (PRE ? kEvalPre : 0), CH>(
+        cc, mr, dm, fref, x, t < T ? u : nullptr, xnext, cost, DIFF ? &kd : nullptr, nullptr,
+        PRE ? a.dyn + tb * dyn_len_c(NJ) : nullptr);
     double *xn = a.xnext + tb * NX;
     ASLR_UNROLL for (int i = 0; i < NX; ++i) xn[i] = xnext[i];
     a.cost[tb] = cost;

@@ -1,5 +1,6 @@
 // calc / calcDiff kernels instantiated for nj = 7
 #include "aslr_calc.inc.hpp"
+#include "aslr_calc_team.inc.hpp"
 
 namespace aslr {
 
@@ -7,7 +8,13 @@ int launch_calc_nj7(const KArgs &k, int dam, bool diff, int mode, double th_gapt
   dim3 grid((k.B + 63) / 64, k.T + 1), block(64);
   if (dam == ASLR_DAM_SEA) {
     {
-      if (diff) hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_SEA, true, false>), grid, block, 0, st, k, mode, th_gaptol);
+      if (diff) { // rigid-body part by 8-lane teams (aslr_calc_team.inc.hpp), then products + costs + record per lane
+        const dim3 tgrid((k.B + 7) / 8, k.T + 1);
+        hipLaunchKernelGGL((dyn_team_kernel<7, 0>), tgrid, block, 0, st, k, mode);
+        hipLaunchKernelGGL((dyn_team_kernel<7, 1>), tgrid, block, 0, st, k, mode);
+        hipLaunchKernelGGL((dyn_team_kernel<7, 2>), tgrid, block, 0, st, k, mode);
+        hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_SEA, true, false, true>), grid, block, 0, st, k, mode, th_gaptol);
+      }
       else hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_SEA, false, false>), grid, block, 0, st, k, mode, th_gaptol);
     }
     HIP_TRY(hipGetLastError());

@@ -802,6 +802,7 @@ struct ModelRegs {
 constexpr int kEvalDyn = 1;  // xnext (dynamics + Euler step)
 constexpr int kEvalCost = 2; // cost
 constexpr int kEvalDiff = 4; // compact derivatives (implies both of the above)
+constexpr int kEvalPre = 8;  // the rigid-body part (xout, M^-1, dtau/dq, dtau/dv) is read from `pre` (DYN region)
 
 // calc (+ calcDiff): x[4NJ], u[NU] -> xnext, cost (+ compact derivatives).
 // u == nullptr selects the model's "u is None" default (terminal node).
@@ -811,11 +812,12 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
                         const DevModel &dm, const double *frame_ref,
                         const double (&x)[4 * NJ], const double *u_in, double (&xnext)[4 * NJ],
                         double &cost_out, KnotDiff<NJ, ModelDims<NJ, DAM>::nu> *kd,
-                        double *xout_o = nullptr) {
+                        double *xout_o = nullptr, const double *pre = nullptr) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
   constexpr bool DIFF = (WHAT & kEvalDiff) != 0;
   constexpr bool DYN = DIFF || (WHAT & kEvalDyn) != 0;
   constexpr bool COST = DIFF || (WHAT & kEvalCost) != 0;
+  constexpr bool PRE = (WHAT & kEvalPre) != 0;
   const aslr_model_t &m = dm.m;
   double u[NU];
   if (u_in) {
@@ -849,20 +851,25 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
       ASLR_UNROLL for (int j = 0; j < NJ; ++j) s += Kmat[i][j] * dqm[j];
       tau_c[i] = s;
     }
-    double M[NJ][NJ], Minv[NJ][NJ], nle[NJ];
-    ch.nle(v, nle);
-    ch.mass(M);
-    spd_inverse_fast<NJ>(M, Minv);
-
-    double xout[2 * NJ];
-    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
-      double s = 0.0, s2 = 0.0;
-      ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
-        s += Minv[i][j] * (-nle[j] - tau_c[j]);
-        s2 += mr.Binv[i][j] * (tau_m[j] + tau_c[j]);
+    double Minv[NJ][NJ], xout[2 * NJ];
+    if constexpr (PRE) {
+      ASLR_UNROLL for (int i = 0; i < 2 * NJ; ++i) xout[i] = pre[i];
+      ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+        ASLR_UNROLL for (int j = 0; j < NJ; ++j) Minv[i][j] = pre[2 * NJ + i * NJ + j];
+    } else {
+      double M[NJ][NJ], nle[NJ];
+      ch.nle(v, nle);
+      ch.mass(M);
+      spd_inverse_fast<NJ>(M, Minv);
+      ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+        double s = 0.0, s2 = 0.0;
+        ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+          s += Minv[i][j] * (-nle[j] - tau_c[j]);
+          s2 += mr.Binv[i][j] * (tau_m[j] + tau_c[j]);
+        }
+        xout[i] = s;
+        xout[NJ + i] = s2;
       }
-      xout[i] = s;
-      xout[NJ + i] = s2;
     }
     if (xout_o) {
       ASLR_UNROLL for (int i = 0; i < 2 * NJ; ++i) xout_o[i] = xout[i];
@@ -876,7 +883,15 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
 
     if (DIFF) {
       double ddq[NJ][NJ], ddv[NJ][NJ];
-      ch.rnea_derivatives(v, xout, ddq, ddv);
+      if constexpr (PRE) {
+        ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+          ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+            ddq[i][j] = pre[2 * NJ + NJ * NJ + i * NJ + j];
+            ddv[i][j] = pre[2 * NJ + 2 * NJ * NJ + i * NJ + j];
+          }
+      } else {
+        ch.rnea_derivatives(v, xout, ddq, ddv);
+      }
       ASLR_UNROLL for (int i = 0; i < NJ; ++i)
         ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
           double sq = 0.0, sk = 0.0, sv = 0.0, bk = 0.0;

@@ -50,32 +50,49 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
   const typename CH::Consts cc(D);
   ModelRegs<NJ, NU> mr;
   int m_loaded = -1;
-  // inputs of knot 0
-  double xr[NX], ur[NU], kr[NU], fg[NX], vf[NX], Kr[NU][NX];
-  int mi;
-  auto load_knot = [&](int t) {
-    const size_t tb = (size_t)t * B + b;
-    ASLR_UNROLL for (int i = 0; i < NX; ++i) xr[i] = a.xs[tb * NX + i];
-    if (use_gaps) { ASLR_UNROLL for (int i = 0; i < NX; ++i) fg[i] = a.gaps[tb * NX + i]; }
-    if (need_dv) { ASLR_UNROLL for (int i = 0; i < NX; ++i) vf[i] = a.vxxf[tb * NX + i]; }
-    mi = a.node_model[t];
-    if (t < T) {
-      ASLR_UNROLL for (int i = 0; i < NU; ++i) { ur[i] = a.us[tb * NU + i]; kr[i] = a.kff[tb * NU + i]; }
-      const double *Kg = a.kgain + tb * NU * NX;
-      ASLR_UNROLL for (int i = 0; i < NU; ++i)
-        ASLR_UNROLL for (int jx = 0; jx < NX; ++jx) Kr[i][jx] = Kg[i * NX + jx];
+  // Per-knot inputs shared by the step lengths of a trajectory -- [K | xs | us | k | gaps | Vxx f] -- are loaded
+  // ONCE per team (element lt + 16 q by lane lt, one knot ahead) and staged in LDS, instead of every lane
+  // loading all of them (16 x fewer load instructions, and no K double buffer in registers).
+  constexpr int oK = 0, oXr = oK + NU * NX, oU = oXr + NX, oKf = oU + NU, oFg = oKf + NU, oVf = oFg + NX,
+                NE = FDDP ? oVf + NX : oFg, NSLOT = (NE + TEAM - 1) / TEAM, STG = NSLOT * TEAM;
+  __shared__ double stg_all[TPW][STG];
+  double *stg = stg_all[team];
+  const double *sp0[NSLOT];
+  size_t sstr[NSLOT];
+  bool son[NSLOT], sctl[NSLOT];
+  ASLR_UNROLL for (int q = 0; q < NSLOT; ++q) {
+    const int idx = al + TEAM * q;
+    sp0[q] = a.xs; sstr[q] = 0; son[q] = false; sctl[q] = false;
+    if (idx < oXr) { sp0[q] = a.kgain + (size_t)b * NU * NX + idx; sstr[q] = (size_t)B * NU * NX; son[q] = true; sctl[q] = true; }
+    else if (idx < oU) { sp0[q] = a.xs + (size_t)b * NX + (idx - oXr); sstr[q] = (size_t)B * NX; son[q] = true; }
+    else if (idx < oKf) { sp0[q] = a.us + (size_t)b * NU + (idx - oU); sstr[q] = (size_t)B * NU; son[q] = true; sctl[q] = true; }
+    else if (idx < oFg) { sp0[q] = a.kff + (size_t)b * NU + (idx - oKf); sstr[q] = (size_t)B * NU; son[q] = true; sctl[q] = true; }
+    else if (FDDP && idx < oVf) { sp0[q] = a.gaps + (size_t)b * NX + (idx - oFg); sstr[q] = (size_t)B * NX; son[q] = need_dv; }
+    else if (FDDP && idx < oVf + NX) { sp0[q] = a.vxxf + (size_t)b * NX + (idx - oVf); sstr[q] = (size_t)B * NX; son[q] = need_dv; }
+  }
+  double pf[NSLOT];
+  int mi_next = 0;
+  auto prefetch = [&](int t) {
+    ASLR_UNROLL for (int q = 0; q < NSLOT; ++q) {
+      pf[q] = 0.0;
+      if (son[q] && (!sctl[q] || t < T)) pf[q] = sp0[q][(size_t)t * sstr[q]];
     }
+    mi_next = a.node_model[t];
   };
-  ASLR_UNROLL for (int i = 0; i < NX; ++i) { fg[i] = 0.0; vf[i] = 0.0; }
-  load_knot(0);
+  prefetch(0);
   for (int t = 0; t <= T; ++t) {
     const size_t tb = (size_t)t * B + b;
+    wave_sync(); // the previous knot's readers of the stage are done
+    ASLR_UNROLL for (int q = 0; q < NSLOT; ++q) stg[al + TEAM * q] = pf[q];
+    const int mi = mi_next;
+    wave_sync();
+    if (t < T) prefetch(t + 1); // in flight while knot t computes
     double dx[NX];
-    if (use_gaps) { ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = x[i] + fg[i] * (alpha - 1.0); }
-    ASLR_UNROLL for (int i = 0; i < NX; ++i) dx[i] = x[i] - xr[i];
+    if (use_gaps) { ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = x[i] + stg[oFg + i] * (alpha - 1.0); }
+    ASLR_UNROLL for (int i = 0; i < NX; ++i) dx[i] = x[i] - stg[oXr + i];
     if (need_dv) { // dv -= fs . Vxx (xs - xs_try)
       double s = 0.0;
-      ASLR_UNROLL for (int i = 0; i < NX; ++i) s += vf[i] * (xr[i] - x[i]);
+      ASLR_UNROLL for (int i = 0; i < NX; ++i) s += stg[oVf + i] * (stg[oXr + i] - x[i]);
       dv -= s;
     }
     if (lane_on) {
@@ -85,8 +102,8 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
     if (t == T) break;
     double u[NU];
     ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-      double s = ur[i] - kr[i] * alpha;
-      ASLR_UNROLL for (int jx = 0; jx < NX; ++jx) s -= Kr[i][jx] * dx[jx];
+      double s = stg[oU + i] - stg[oKf + i] * alpha;
+      ASLR_UNROLL for (int jx = 0; jx < NX; ++jx) s -= stg[oK + i * NX + jx] * dx[jx];
       u[i] = s;
     }
     const int m_now = mi;
@@ -97,7 +114,6 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
       double *o = a.us_try + ((size_t)ai * TB + tb) * NU;
       ASLR_UNROLL for (int i = 0; i < NU; ++i) o[i] = u[i];
     }
-    load_knot(t + 1); // in flight while the dynamics of knot t computes
     const DevModel &dm = D.models[m_now];
     if (m_now != m_loaded) { mr.load(dm); m_loaded = m_now; } // wave-uniform
     double xnext[NX], c;

@@ -178,6 +178,8 @@ typedef struct aslr_solver_params {
  *   US_TRY  [NALPHA][T][B][nu]
  *   VXXF    [T+1][B][nx]        Vxx[t] fs[t] (FDDP expected improvement)
  *   COST_TRY [NALPHA][T+1][B]   node costs of every line-search candidate
+ *   DYN     [T+1][B][2nj+3nj^2] rigid-body intermediates of calcDiff (xout, M^-1, dtau/dq, dtau/dv) handed from
+ *                               the team kernel to the record assembly; only for chains with nj > 2 (else empty)
  *   TRAJ_F  [ASLR_TF_COUNT][B]  per-trajectory doubles (ASLR_TF_*)
  *   TRAJ_I  [ASLR_TI_COUNT][B]  per-trajectory int32   (ASLR_TI_*)
  */
@@ -185,7 +187,7 @@ enum aslr_region_id {
   ASLR_R_XS = 0, ASLR_R_US, ASLR_R_XNEXT, ASLR_R_COST, ASLR_R_DERIV, ASLR_R_GAPS,
   ASLR_R_KGAIN, ASLR_R_KFF, ASLR_R_QU, ASLR_R_VX, ASLR_R_VXX, ASLR_R_XS_TRY, ASLR_R_US_TRY,
   ASLR_R_TRAJ_F, ASLR_R_TRAJ_I, ASLR_R_X0, ASLR_R_FRAME_REF, ASLR_R_VXXF, ASLR_R_DESC,
-  ASLR_R_NODE_MODEL, ASLR_R_COST_TRY, ASLR_R_COUNT
+  ASLR_R_NODE_MODEL, ASLR_R_COST_TRY, ASLR_R_DYN, ASLR_R_COUNT
 };
 
 /* rows of TRAJ_F */

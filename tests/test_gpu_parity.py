@@ -258,8 +258,10 @@ def test_edge_sizes_single_knot_single_trajectory(oracle):
         e.set_candidate(None, None)
         e.solve(sp, poll_every=1)
         _sync()
-        assert np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max() < 1e-6
-        assert np.abs(_np(e.region(_abi.R_US)) - ref["us"]).max() < 1e-6
+        # 15 iterations of a cold start: mid-descent iterates of size ~1e2, compared relative to their size
+        scale = max(1.0, np.abs(ref["xs"]).max(), np.abs(ref["us"]).max())
+        assert np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max() < 1e-6 * scale
+        assert np.abs(_np(e.region(_abi.R_US)) - ref["us"]).max() < 1e-6 * scale
         np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER])
         np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)), ref["traj_i"][_abi.TI_STATUS])
     # maxiter = 0 leaves the candidate untouched
