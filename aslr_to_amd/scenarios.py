@@ -9,7 +9,7 @@ import numpy as np
 from . import example_robot_data
 from .crocoddyl import (ActivationModelWeightedQuad, CostModelResidual, CostModelSum, ResidualModelControl,
                         ResidualModelState)
-from .models import (ASRActuation, ActuationModelDoublePendulum, CostModelDoublePendulum,
+from .models import (ASRActuation, ActuationModelDoublePendulum, CostModelDoublePendulum, CostModelStiffness,
                      DifferentialFreeASRFwdDynamicsModel, DifferentialFreeFwdDynamicsModelVSA,
                      IntegratedActionModelEulerASR, ResidualModelFramePlacementASR, StateMultibodyASR,
                      VSAASRActuation)
@@ -58,6 +58,42 @@ def two_dof_vsa_boxddp(B=1, T=100, seed=0):
     x0, refs = _batch_inputs(B, seed, 2, p_nom)
     return dict(x0=x0, running=[runningModel] * T, terminal=terminalModel, frame_refs=refs, solver="SolverBoxDDP",
                 maxiter=400, th_stop=1e-7, name="two_dof_vsa_boxddp")
+
+
+def two_dof_vsa_modified(B=1, T=200, seed=0):
+    """examples/two_dof_vsa_modified.py:14-67: the VSA arm with the linear stiffness cost (stiffness_cost.py), a
+    control regulariser on the motor torques only, and the stiffness bounded below by 0.002 (SURVEY.md 8(f) #4)."""
+    robot_model = example_robot_data.load('asr_twodof').model
+    robot_model.gravity.linear = np.array([9.81, 0, 0])
+    state = StateMultibodyASR(robot_model)
+    actuation = VSAASRActuation(state)
+    nu = 2 * actuation.nu
+    p_nom = np.array([.01, .2, .18])
+    framePlacementResidual = ResidualModelFramePlacementASR(state, robot_model.getFrameId("EE"), SE3(np.eye(3), p_nom), nu)
+    goalTrackingCost = CostModelResidual(state, framePlacementResidual)
+    xActivation = ActivationModelWeightedQuad(np.array([1e0] * 2 + [1e0] * 2 + [1e0] * robot_model.nv + [1e0] * robot_model.nv))
+    xRegCost = CostModelResidual(state, xActivation, ResidualModelState(state, state.zero(), nu))
+    uActivation = ActivationModelWeightedQuad(np.array([1e0] + [1e0] + [0] * 2))
+    uRegCost = CostModelResidual(state, uActivation, ResidualModelControl(state, nu))
+    lamda = 10
+    Kref = 0.002 * np.ones(int(nu / 2))
+    vsaCost = CostModelStiffness(state, nu, lamda, Kref)
+    runningCostModel = CostModelSum(state, nu)
+    terminalCostModel = CostModelSum(state, nu)
+    runningCostModel.addCost("gripperPose", goalTrackingCost, 1e0)
+    runningCostModel.addCost("xReg", xRegCost, 1e-3)
+    runningCostModel.addCost("uReg", uRegCost, 1e-2)
+    runningCostModel.addCost("vsa", vsaCost, 1e-2)
+    terminalCostModel.addCost("gripperPose", goalTrackingCost, 1e4)
+    Bm = .001 * np.eye(int(state.nv / 2))
+    dt = 1e-2
+    runningModel = IntegratedActionModelEulerASR(DifferentialFreeFwdDynamicsModelVSA(state, actuation, runningCostModel, Bm), dt)
+    terminalModel = IntegratedActionModelEulerASR(DifferentialFreeFwdDynamicsModelVSA(state, actuation, terminalCostModel, Bm), 0)
+    runningModel.u_lb = np.array([-100, -100, 0.002, 0.002])
+    runningModel.u_ub = np.array([100, 100, 100, 100])
+    x0, refs = _batch_inputs(B, seed, 2, p_nom)
+    return dict(x0=x0, running=[runningModel] * T, terminal=terminalModel, frame_refs=refs, solver="SolverBoxDDP",
+                maxiter=400, th_stop=1e-7, name="two_dof_vsa_modified")
 
 
 def two_dof_sea(B=1, T=100, seed=0):
@@ -146,7 +182,8 @@ def talos_arm_sea(B=1, T=150, seed=0):
                 maxiter=100, th_stop=1e-7, name="talos_arm_sea")
 
 
-SCENARIOS = {"two_dof_vsa_boxddp": two_dof_vsa_boxddp, "two_dof_sea": two_dof_sea,
+SCENARIOS = {"two_dof_vsa_boxddp": two_dof_vsa_boxddp, "two_dof_vsa_modified": two_dof_vsa_modified,
+             "two_dof_sea": two_dof_sea,
              "double_pendulum": double_pendulum, "talos_arm_sea": talos_arm_sea}
 
 

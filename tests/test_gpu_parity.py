@@ -184,6 +184,35 @@ def test_solve_matches_oracle(oracle, name, kw, solver):
     assert (it_g == it_r)[conv].all()
 
 
+def test_vsa_modified_example_first_iterations_match_oracle(oracle):
+    """examples/two_dof_vsa_modified.py (linear stiffness cost, sigma >= 0.002).  Its Quu is
+    singular along the stiffness directions (no control regulariser there): one ill-conditioned BoxQP step
+    amplifies rounding differences by ~1e6 (tools/diverge.py: 7e-12 -> 2e-5 at iteration 9 of trajectory 0 while
+    status, iteration counts and regularisation keep matching through iteration 25), and the
+    solve runs into its iteration cap.  Parity of the iterates is therefore checked on the first 8 iterations,
+    the solver state on the first 25."""
+    sc = scenarios.two_dof_vsa_modified(B=6, T=60)
+    low = scenarios.lower(sc)
+    e = _engine(low)
+    for maxiter in (25, 8):
+        sp = scenarios.solver_params(sc, maxiter=maxiter)
+        ref = oracle.solve(low, sp)
+        e.set_candidate(None, None)
+        e.solve(sp, poll_every=5)
+        _sync()
+        np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER])
+        np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)), ref["traj_i"][_abi.TI_STATUS])
+        np.testing.assert_allclose(_np(e.traj_f(_abi.TF_XREG)), ref["traj_f"][_abi.TF_XREG], rtol=0)
+        if maxiter == 8:
+            np.testing.assert_allclose(_np(e.traj_f(_abi.TF_STEP)), ref["traj_f"][_abi.TF_STEP], rtol=0)
+    scale = max(1.0, np.abs(ref["xs"]).max(), np.abs(ref["us"]).max())
+    dx = np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max()
+    du = np.abs(_np(e.region(_abi.R_US)) - ref["us"]).max()
+    print("vsa_modified: dx %.2e du %.2e scale %.2e" % (dx, du, scale))
+    assert dx < 1e-6 * scale and du < 1e-6 * scale
+    assert (_np(e.region(_abi.R_US))[..., 2:] >= 0.002).all()   # the stiffness bound holds
+
+
 def _indefinite_sea(B, T, cost_name, weight):
     """SEA problem with one NEGATIVE cost weight: Quu / Vxx turn indefinite, so backward passes fail
     (Cholesky "backward_error" -> increaseRegularization -> retry without recalc) and the
