@@ -53,6 +53,8 @@ def all_reduce_stats(vec, group=None):
     """SUM-all-reduce the stats vector (no-op without an initialised process group) -> dict."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "gloo":
+            vec = vec.cpu()  # gloo reduces host tensors (CPU tests, single-GPU rehearsals of the N > 1 path)
         dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
     h = vec.detach().cpu().tolist()
     out = dict(zip(STAT_FIELDS, h))
@@ -67,6 +69,8 @@ def max_over_ranks(value, device=None, group=None):
     import torch.distributed as dist
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "gloo":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 

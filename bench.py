@@ -97,12 +97,15 @@ def main():
     from aslr_to_amd import _abi, dist, scenarios
     from aslr_to_amd.crocoddyl import ShootingProblem
 
-    rank, world, local = dist.init_from_env()
+    # ASLR_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo for the two reductions -- rehearses the N > 1 code
+    # path on a one-GPU box (its throughput figure is meaningless: the ranks share the GPU)
+    rehearsal = os.environ.get("ASLR_BENCH_REHEARSAL") == "1"
+    rank, world, local = dist.init_from_env("gloo" if rehearsal else None)
     if world != max(1, args.gpus) and world > 1:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local if world > 1 else 0)
+    torch.cuda.set_device(local if world > 1 and not rehearsal else 0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     Bg = args.batch_per_gpu
@@ -156,7 +159,7 @@ def main():
         "metric": "knot-steps/s (batched BoxDDP, 2-DoF VSA, T=100, 4096 trajectories per GPU)",
         "value": value, "unit": "knot-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearsal else ""),
         "config": {"workload": "two_dof_vsa_boxddp (examples/two_dof_vsa_boxddp.py, T=100): SolverBoxDDP, "
                                "cold start, fixed-iteration mode, full 10-alpha line search every iteration",
                    "batch_per_gpu": Bg, "global_batch": Bg * world, "T": T, "nx": e.nx, "nu": e.nu,
