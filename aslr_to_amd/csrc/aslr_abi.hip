@@ -324,6 +324,8 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   if (e == hipSuccess) e = hipMemsetAsync(reg(ASLR_R_TRAJ_I), 0, p->regions[ASLR_R_TRAJ_I].bytes, st);
   if (e == hipSuccess) e = hipMemsetAsync(reg(ASLR_R_TRAJ_F), 0, p->regions[ASLR_R_TRAJ_F].bytes, st);
   if (e == hipSuccess) e = hipMemsetAsync(reg(ASLR_R_GAPS), 0, p->regions[ASLR_R_GAPS].bytes, st);
+  // calc_kernel never rewrites the record chunks that are structurally zero (Lxu, the empty parts of Lxx / Luu)
+  if (e == hipSuccess) e = hipMemsetAsync(reg(ASLR_R_DERIV), 0, p->regions[ASLR_R_DERIV].bytes, st);
   if (e == hipSuccess) e = hipMemsetAsync(reg(ASLR_R_KFF), 0, p->regions[ASLR_R_KFF].bytes, st);
   if (e == hipSuccess) e = hipMemsetAsync(reg(ASLR_R_VXXF), 0, p->regions[ASLR_R_VXXF].bytes, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st); // the host staging buffers die below

@@ -77,12 +77,14 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
     const typename CH::Consts cc(D);
     ModelRegs<NJ, NU> mr;
     mr.load(dm);
-    knot_eval<NJ, DAM, (DIFF ? kEvalDiff : (kEvalDyn | kEvalCost)) | (PRE ? kEvalPre : 0), CH>(
-        cc, mr, dm, fref, x, t < T ? u : nullptr, xnext, cost, DIFF ? &kd : nullptr, nullptr,
-        PRE ? a.dyn + tb * dyn_len_c(NJ) : nullptr);
+    // PRE (large chain): the evaluation is split -- dynamics derivatives first, their part of the record streamed
+    // out, then the cost stack -- so that the ~400 doubles of the compact derivative set are never all live
+    constexpr int what = (DIFF ? kEvalDiff : (kEvalDyn | kEvalCost)) | (PRE ? (kEvalPre | kEvalSkipCost) : 0);
+    knot_eval<NJ, DAM, what, CH>(cc, mr, dm, fref, x, t < T ? u : nullptr, xnext, cost, DIFF ? &kd : nullptr, nullptr,
+                                 PRE ? a.dyn + tb * dyn_len_c(NJ) : nullptr);
     double *xn = a.xnext + tb * NX;
     ASLR_UNROLL for (int i = 0; i < NX; ++i) xn[i] = xnext[i];
-    a.cost[tb] = cost;
+    if constexpr (!PRE) a.cost[tb] = cost;
     // gaps (SolverDDP::calcDiff): f[0] = x0 - xs[0]; f[t+1] = xnext_t - xs[t+1]
     if ((mode & kModeSolver) && !feasible) {
       double mx = 0.0;
@@ -111,10 +113,14 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
   if constexpr (DIFF) {
   // ---- stream the record out: 16 doubles per knot per flush, transposed through LDS ----
   act[lane] = compute ? 1 : 0;
+  const bool all_on = __ballot(compute) == ~0ull; // the usual case: no per-record test in the store loop
   const double dt = dm.m.dt;
   double *rec0 = a.deriv + ((size_t)t * B + b0) * REC;
-  static_for<0, REC / kChunk>([&](auto cc) {
+  auto flush_chunk = [&](auto cc) {
     constexpr int c = decltype(cc)::value;
+    // chunks of structural zeros (all of Lxu, most of Lxx / Luu for the larger chain) were written once, by the
+    // zero fill of DERIV at problem creation
+    if constexpr (rec_chunk_is_zero<NJ, NU, c, kChunk>()) return;
     if (compute) {
       static_for<0, kChunk>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
@@ -124,7 +130,7 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
     wave_sync();
     ASLR_UNROLL for (int i = 0; i < kChunk / 2; ++i) {
       const int idx = lane + 64 * i, k = idx >> 3, e = (idx & 7) * 2;
-      if (act[k]) {
+      if (all_on || act[k]) {
         double2 v2;
         v2.x = sm[k * kLdsStride + e];
         v2.y = sm[k * kLdsStride + e + 1];
@@ -136,7 +142,22 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
       }
     }
     wave_sync();
-  });
+  };
+  // chunks made of Fx / Fu only come first; with PRE the cost stack is evaluated between the two groups
+  constexpr int C1 = PRE ? RL::oLxx / kChunk : 0;
+  static_for<0, C1>(flush_chunk);
+  if constexpr (PRE) {
+    if (compute) {
+      using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
+      const typename CH::Consts cc(D);
+      ModelRegs<NJ, NU> mr;
+      mr.load(dm);
+      double xn2[NX], cost2 = 0.0;
+      knot_eval<NJ, DAM, kEvalDiff | kEvalSkipDyn, CH>(cc, mr, dm, fref, x, t < T ? u : nullptr, xn2, cost2, &kd);
+      a.cost[(size_t)t * B + b] = cost2;
+    }
+  }
+  static_for<C1, REC / kChunk>(flush_chunk);
   }
 }
 

@@ -803,6 +803,8 @@ constexpr int kEvalDyn = 1;  // xnext (dynamics + Euler step)
 constexpr int kEvalCost = 2; // cost
 constexpr int kEvalDiff = 4; // compact derivatives (implies both of the above)
 constexpr int kEvalPre = 8;  // the rigid-body part (xout, M^-1, dtau/dq, dtau/dv) is read from `pre` (DYN region)
+constexpr int kEvalSkipCost = 16; // with kEvalDiff: dynamics and its derivatives only (first half of a split evaluation)
+constexpr int kEvalSkipDyn = 32;  // with kEvalDiff: cost stack and its derivatives only (second half)
 
 // calc (+ calcDiff): x[4NJ], u[NU] -> xnext, cost (+ compact derivatives).
 // u == nullptr selects the model's "u is None" default (terminal node).
@@ -815,8 +817,8 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
                         double *xout_o = nullptr, const double *pre = nullptr) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
   constexpr bool DIFF = (WHAT & kEvalDiff) != 0;
-  constexpr bool DYN = DIFF || (WHAT & kEvalDyn) != 0;
-  constexpr bool COST = DIFF || (WHAT & kEvalCost) != 0;
+  constexpr bool DYN = (DIFF || (WHAT & kEvalDyn) != 0) && (WHAT & kEvalSkipDyn) == 0;
+  constexpr bool COST = (DIFF || (WHAT & kEvalCost) != 0) && (WHAT & kEvalSkipCost) == 0;
   constexpr bool PRE = (WHAT & kEvalPre) != 0;
   const aslr_model_t &m = dm.m;
   double u[NU];
@@ -1089,6 +1091,30 @@ ASLR_DEV double rec_elem(const KnotDiff<NJ, NU> &k, double dt) {
   } else {
     return 0.0;
   }
+}
+
+// structural zero test of record element E: true when rec_elem<NJ, NU, E>() is 0.0 whatever the knot (the DERIV
+// region is zero-filled at problem creation, so a 16-double chunk made of such elements never needs writing)
+template <int NJ, int NU, int E>
+constexpr bool rec_elem_is_zero() {
+  using L = RecLayout<NJ, NU>;
+  constexpr int NX = L::NX;
+  if (E < L::oLxx) return false;                       // Fx / Fu: data (or 1, dt) everywhere that matters
+  if (E < L::oLxu) {                                   // Lxx: the nj x nj block and the diagonal
+    constexpr int e = E - L::oLxx, r = e / NX, cc = e % NX;
+    return !((r < NJ && cc < NJ) || r == cc);
+  }
+  if (E < L::oLuu) return true;                        // Lxu
+  if (E < L::oLx) {                                    // Luu: diagonal
+    constexpr int e = E - L::oLuu, r = e / NU, cc = e % NU;
+    return r != cc;
+  }
+  return E >= L::oEnd;                                 // Lx, Lu: data; padding: zero
+}
+template <int NJ, int NU, int C, int CHUNK, int I = 0>
+constexpr bool rec_chunk_is_zero() {
+  if constexpr (I == CHUNK) return true;
+  else return rec_elem_is_zero<NJ, NU, C * CHUNK + I>() && rec_chunk_is_zero<NJ, NU, C, CHUNK, I + 1>();
 }
 
 // compile-time loop helper
