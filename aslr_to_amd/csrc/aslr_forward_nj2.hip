@@ -23,21 +23,7 @@ int launch_forward_nj2(const KArgs &k, int dam, const SolverDev &sd, const Model
   if (dam == ASLR_DAM_VSA) {
     if (k.planar) {
       if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, true, true>), grid, block, 0, st, k, sd, lim);
-      else {
-        static hipStream_t s2 = nullptr; static hipEvent_t e0, e1;
-        const char *ov = getenv("ASLR_FWD_OVERLAP_TEST");
-        if (ov && atoi(ov)) {
-          if (!s2) { hipStreamCreateWithFlags(&s2, hipStreamNonBlocking); hipEventCreateWithFlags(&e0, hipEventDisableTiming); hipEventCreateWithFlags(&e1, hipEventDisableTiming); }
-          hipEventRecord(e0, st); hipStreamWaitEvent(s2, e0, 0);
-          hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, true, false>), grid, block, 0, st, k, sd, lim);
-          hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_VSA, true>), cgrid, cblock, 0, s2, k, sd);
-          hipEventRecord(e1, s2); hipStreamWaitEvent(st, e1, 0);
-          hipLaunchKernelGGL((sum_cost_kernel<2>), ugrid, block, 0, st, k, sd);
-          hipLaunchKernelGGL((select_kernel<2>), sgrid, block, 0, st, k, sd);
-          return ASLR_OK;
-        }
-        hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, true, false>), grid, block, 0, st, k, sd, lim);
-      }
+      else hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, true, false>), grid, block, 0, st, k, sd, lim);
       hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_VSA, true>), cgrid, cblock, 0, st, k, sd);
     } else {
       if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, false, true>), grid, block, 0, st, k, sd, lim);
