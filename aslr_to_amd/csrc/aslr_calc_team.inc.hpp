@@ -22,7 +22,7 @@ namespace aslr {
 // the joints upstream of j carry exact zeros, the special values at i == j are selected.
 // ws (LDS): per joint [v | h | F | Xv | Xa], 6 doubles each (lin, ang).
 template <int NJ, int KIND>
-ASLR_DEV void rnea_tangent_lds(const aslr_chain_t &c, const double *Rl, const double *ws, const double *velL, int j,
+ASLR_DEV void rnea_tangent_lds(chain_cp c, const double *Rl, const double *ws, const double *velL, int j,
                                               double *colL) {
   double vv[NJ], col[NJ];
   ASLR_UNROLL for (int i = 0; i < NJ; ++i) vv[i] = velL[i];
@@ -39,8 +39,8 @@ ASLR_DEV void rnea_tangent_lds(const aslr_chain_t &c, const double *Rl, const do
   ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
     SE3d X;
     X.R = m3(Rl + 9 * i);
-    X.p = v3(c.joint_p[i]);
-    const V3 ax = v3(c.axis[i]);
+    X.p = v3(c->joint_p[i]);
+    const V3 ax = v3(c->axis[i]);
     const SV Si = SV{V3{0, 0, 0}, ax};
     const SV vi = sv_at(i, 0), hi = sv_at(i, 1);
     const bool at = i == j;
@@ -51,19 +51,19 @@ ASLR_DEV void rnea_tangent_lds(const aslr_chain_t &c, const double *Rl, const do
     SV dai = sel(at, sa, motion_actinv(X, dap));
     const SV vJ = SV{V3{0, 0, 0}, vv[i] * ax};
     dai = dai + crm(dvi, vJ);
-    const V3 com = v3(c.com[i]);
-    const M3 I = m3(c.inertia[i]);
-    df[i] = inertia_mul(c.mass[i], com, I, dai) + crf(dvi, hi) + crf(vi, inertia_mul(c.mass[i], com, I, dvi));
+    const V3 com = v3(c->com[i]);
+    const M3 I = m3(c->inertia[i]);
+    df[i] = inertia_mul(c->mass[i], com, I, dai) + crf(dvi, hi) + crf(vi, inertia_mul(c->mass[i], com, I, dvi));
     dvp = dvi;
     dap = dai;
   }
   ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
-    const V3 ax = v3(c.axis[i]);
+    const V3 ax = v3(c->axis[i]);
     col[i] = dot(ax, df[i].ang);
     if (i > 0) {
       SE3d X;
       X.R = m3(Rl + 9 * i);
-      X.p = v3(c.joint_p[i]);
+      X.p = v3(c->joint_p[i]);
       df[i - 1] = df[i - 1] + force_act(X, df[i]);
       if (KIND == 0) {
         const SV ex = force_act(X, crf(SV{V3{0, 0, 0}, ax}, sv_at(i, 2)));
@@ -76,11 +76,11 @@ ASLR_DEV void rnea_tangent_lds(const aslr_chain_t &c, const double *Rl, const do
 
 // rnea<NJ, true>() with the rotations in LDS; lane `writer` stores what the tangent sweeps need
 template <int NJ>
-ASLR_DEV void rnea_keep_lds(const aslr_chain_t &c, const double *Rl, const double *velL, const double *accL,
+ASLR_DEV void rnea_keep_lds(chain_cp c, const double *Rl, const double *velL, const double *accL,
                                            double *ws, bool writer) {
   double vv[NJ], aa[NJ];
   ASLR_UNROLL for (int i = 0; i < NJ; ++i) { vv[i] = velL[i]; aa[i] = accL[i]; }
-  const V3 grav = v3(c.gravity);
+  const V3 grav = v3(c->gravity);
   auto put = [&](int i, int which, SV s) {
     double *p = ws + 30 * i + 6 * which;
     p[0] = s.lin.x; p[1] = s.lin.y; p[2] = s.lin.z; p[3] = s.ang.x; p[4] = s.ang.y; p[5] = s.ang.z;
@@ -90,18 +90,18 @@ ASLR_DEV void rnea_keep_lds(const aslr_chain_t &c, const double *Rl, const doubl
   ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
     SE3d X;
     X.R = m3(Rl + 9 * i);
-    X.p = v3(c.joint_p[i]);
-    const V3 ax = v3(c.axis[i]);
+    X.p = v3(c->joint_p[i]);
+    const V3 ax = v3(c->axis[i]);
     const SV vJ = SV{V3{0, 0, 0}, vv[i] * ax};
     const SV Xv = motion_actinv(X, vp);
     const SV vi = Xv + vJ;
     const SV Xa = motion_actinv(X, ap);
     SV ai = Xa + crm(vi, vJ);
     ai.ang = ai.ang + aa[i] * ax;
-    const V3 com = v3(c.com[i]);
-    const M3 I = m3(c.inertia[i]);
-    const SV h = inertia_mul(c.mass[i], com, I, vi);
-    f[i] = inertia_mul(c.mass[i], com, I, ai) + crf(vi, h);
+    const V3 com = v3(c->com[i]);
+    const M3 I = m3(c->inertia[i]);
+    const SV h = inertia_mul(c->mass[i], com, I, vi);
+    f[i] = inertia_mul(c->mass[i], com, I, ai) + crf(vi, h);
     if (writer) { put(i, 0, vi); put(i, 1, h); put(i, 3, Xv); put(i, 4, Xa); }
     vp = vi;
     ap = ai;
@@ -110,7 +110,7 @@ ASLR_DEV void rnea_keep_lds(const aslr_chain_t &c, const double *Rl, const doubl
     if (i > 0) {
       SE3d X;
       X.R = m3(Rl + 9 * i);
-      X.p = v3(c.joint_p[i]);
+      X.p = v3(c->joint_p[i]);
       f[i - 1] = f[i - 1] + force_act(X, f[i]);
     }
     if (writer) put(i, 2, f[i]);
@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(64) dyn_team_kernel(KArgs a, int mode) {
   const int cj = jl ? c : NJ - 1;
   const DevDesc &D = *a.desc;
   const aslr_chain_t &ch = D.chain;
+  const chain_cp chc = chain_const(&D.chain);
   const DevModel &dm = D.models[a.node_model[t]];
 
   // ---- x, u of this knot (from the accepted candidate when there is one; the terminal node takes u = 0) ----
@@ -183,13 +184,13 @@ __global__ void __launch_bounds__(64) dyn_team_kernel(KArgs a, int mode) {
   wave_sync();
   double *out = a.dyn + tb * DL;
   if constexpr (PHASE == 0) {
-    const V3 g = v3(ch.gravity);
+    const V3 g = v3(chc->gravity);
     // ---- M columns and nonlinear effects: one RNEA per lane ----
     {
       double vv[NJ], aa[NJ], tau[NJ];
       const bool nl = c == NJ;
       ASLR_UNROLL for (int i = 0; i < NJ; ++i) { vv[i] = nl ? xT[2 * NJ + i] : 0.0; aa[i] = (!nl && i == c) ? 1.0 : 0.0; }
-      rnea_lds<NJ>(ch, RL, vv, aa, nl ? g : V3{0.0, 0.0, 0.0}, tau);
+      rnea_lds<NJ>(chc, RL, vv, aa, nl ? g : V3{0.0, 0.0, 0.0}, tau);
       if (c <= NJ) { ASLR_UNROLL for (int i = 0; i < NJ; ++i) ML[8 * c + i] = tau[i]; }
     }
     wave_sync();
@@ -221,10 +222,10 @@ __global__ void __launch_bounds__(64) dyn_team_kernel(KArgs a, int mode) {
     // ---- RNEA(q, v, a_link) keeping its intermediates, then one tangent sweep per lane ----
     if (jl) xoL[c] = out[c]; // link accelerations of phase 0
     wave_sync();
-    rnea_keep_lds<NJ>(ch, RL, xT + 2 * NJ, xoL, WS, c == 0);
+    rnea_keep_lds<NJ>(chc, RL, xT + 2 * NJ, xoL, WS, c == 0);
     wave_sync();
     double *colL = ML + 8 * c;
-    rnea_tangent_lds<NJ, PHASE - 1>(ch, RL, WS, xT + 2 * NJ, cj, colL);
+    rnea_tangent_lds<NJ, PHASE - 1>(chc, RL, WS, xT + 2 * NJ, cj, colL);
     if (jl && compute) { ASLR_UNROLL for (int i = 0; i < NJ; ++i) out[2 * NJ + PHASE * NJ * NJ + i * NJ + c] = colL[i]; }
   }
 }

@@ -21,36 +21,49 @@
 
 namespace aslr {
 
+// The chain table is read-only for the lifetime of the problem.  Read through the constant address space, its
+// wave-uniform entries are fetched by scalar loads into SGPRs (s_load) instead of one vector load per lane that
+// the compiler must otherwise keep ordered with the kernel's global stores.
+typedef const aslr_chain_t __attribute__((address_space(4))) *chain_cp;
+typedef const double __attribute__((address_space(4))) *cdp;
+ASLR_DEV chain_cp chain_const(const aslr_chain_t *c) { return (chain_cp)c; }
+ASLR_DEV V3 v3(cdp p) { return V3{p[0], p[1], p[2]}; }
+ASLR_DEV M3 m3(cdp p) {
+  M3 m;
+  ASLR_UNROLL for (int i = 0; i < 9; ++i) m.a[i] = p[i];
+  return m;
+}
+
 // RNEA(q, v, a) of rnea<NJ, false>() with the joint rotations read from LDS (Rl[NJ][9], row-major)
 template <int NJ>
-ASLR_DEV void rnea_lds(const aslr_chain_t &c, const double *Rl, const double (&vv)[NJ], const double (&aa)[NJ], V3 grav,
+ASLR_DEV void rnea_lds(chain_cp cp, const double *Rl, const double (&vv)[NJ], const double (&aa)[NJ], V3 grav,
                        double (&tau)[NJ]) {
   SV vp = sv_zero(), ap = SV{neg(grav), V3{0, 0, 0}};
   SV f[NJ];
   ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
     SE3d X;
     X.R = m3(Rl + 9 * i);
-    X.p = v3(c.joint_p[i]);
-    const V3 ax = v3(c.axis[i]);
+    X.p = v3(cp->joint_p[i]);
+    const V3 ax = v3(cp->axis[i]);
     const SV vJ = SV{V3{0, 0, 0}, vv[i] * ax};
     const SV Xv = motion_actinv(X, vp);
     const SV vi = Xv + vJ;
     const SV Xa = motion_actinv(X, ap);
     SV ai = Xa + crm(vi, vJ);
     ai.ang = ai.ang + aa[i] * ax;
-    const V3 com = v3(c.com[i]);
-    const M3 I = m3(c.inertia[i]);
-    const SV h = inertia_mul(c.mass[i], com, I, vi);
-    f[i] = inertia_mul(c.mass[i], com, I, ai) + crf(vi, h);
+    const V3 com = v3(cp->com[i]);
+    const M3 I = m3(cp->inertia[i]);
+    const SV h = inertia_mul(cp->mass[i], com, I, vi);
+    f[i] = inertia_mul(cp->mass[i], com, I, ai) + crf(vi, h);
     vp = vi;
     ap = ai;
   }
   ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
-    tau[i] = dot(v3(c.axis[i]), f[i].ang);
+    tau[i] = dot(v3(cp->axis[i]), f[i].ang);
     if (i > 0) {
       SE3d X;
       X.R = m3(Rl + 9 * i);
-      X.p = v3(c.joint_p[i]);
+      X.p = v3(cp->joint_p[i]);
       f[i - 1] = f[i - 1] + force_act(X, f[i]);
     }
   }
@@ -121,6 +134,7 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
   const int cj = jl ? c : NJ - 1;
   const DevDesc &D = *a.desc;
   const aslr_chain_t &ch = D.chain;
+  const chain_cp chc = chain_const(&D.chain);
   const size_t TB1 = (size_t)(T + 1) * B, TB = (size_t)T * B;
   const unsigned long long team_bits = 0xffull << ((lane >> 3) * 8);
 
@@ -200,7 +214,7 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
     }
     // ---- rotation of joint cj ----
     if (jl) {
-      const M3 R = mul(m3(ch.joint_R[cj]), axis_angle(v3(ch.axis[cj]), xT[cj]));
+      const M3 R = mul(m3(ch.joint_R[cj]), axis_angle(v3(ch.axis[cj]), xT[cj])); // (per-lane joint: vector loads)
       ASLR_UNROLL for (int k = 0; k < 9; ++k) RL[9 * c + k] = R.a[k];
     }
     wave_sync();
@@ -216,9 +230,9 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
       double vv[NJ], aa[NJ], tau[NJ];
       const bool nl = c == NJ;
       ASLR_UNROLL for (int i = 0; i < NJ; ++i) { vv[i] = nl ? xT[2 * NJ + i] : 0.0; aa[i] = (!nl && i == c) ? 1.0 : 0.0; }
-      const V3 g = v3(ch.gravity);
+      const V3 g = v3(chc->gravity);
       const V3 grav = nl ? g : V3{0.0, 0.0, 0.0};
-      rnea_lds<NJ>(ch, RL, vv, aa, grav, tau);
+      rnea_lds<NJ>(chc, RL, vv, aa, grav, tau);
       ASLR_UNROLL for (int i = 0; i < NJ; ++i) ML[8 * c + i] = tau[i];
     }
     wave_sync();
