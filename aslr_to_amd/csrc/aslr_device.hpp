@@ -121,6 +121,18 @@ ASLR_DEV M3 m3(const double *p) {
   ASLR_UNROLL for (int i = 0; i < 9; ++i) R.a[i] = p[i];
   return R;
 }
+// The chain table is read-only for the lifetime of the problem.  Read through the constant address space, its
+// wave-uniform entries are fetched by scalar loads into SGPRs (s_load) instead of one vector load per lane that
+// the compiler must otherwise keep ordered with the kernel's global stores.
+typedef const aslr_chain_t __attribute__((address_space(4))) *chain_cp;
+typedef const double __attribute__((address_space(4))) *cdp;
+ASLR_DEV chain_cp chain_const(const aslr_chain_t *c) { return (chain_cp)c; }
+ASLR_DEV V3 v3(cdp p) { return V3{p[0], p[1], p[2]}; }
+ASLR_DEV M3 m3(cdp p) {
+  M3 m;
+  ASLR_UNROLL for (int i = 0; i < 9; ++i) m.a[i] = p[i];
+  return m;
+}
 ASLR_DEV SV operator+(SV a, SV b) { return SV{a.lin + b.lin, a.ang + b.ang}; }
 ASLR_DEV SV sv_zero() { return SV{V3{0, 0, 0}, V3{0, 0, 0}}; }
 // Rodrigues rotation about a unit axis (JointModelRevoluteUnaligned)
@@ -356,28 +368,28 @@ struct RneaWs {
 };
 
 template <int NJ, bool KEEP>
-ASLR_DEV void rnea(const aslr_chain_t &c, const Kin<NJ> &k, const double *v, const double *a, V3 grav,
+ASLR_DEV void rnea(chain_cp c, const Kin<NJ> &k, const double *v, const double *a, V3 grav,
                    double *tau, RneaWs<NJ> &w) {
   SV vp = sv_zero(), ap = SV{neg(grav), V3{0, 0, 0}};
   SV f[NJ];
   ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
-    const V3 ax = v3(c.axis[i]);
+    const V3 ax = v3(c->axis[i]);
     const SV vJ = SV{V3{0, 0, 0}, v[i] * ax};
     const SV Xv = motion_actinv(k.liMi[i], vp);
     const SV vi = Xv + vJ;
     const SV Xa = motion_actinv(k.liMi[i], ap);
     SV ai = Xa + crm(vi, vJ);
     ai.ang = ai.ang + a[i] * ax;
-    const V3 com = v3(c.com[i]);
-    const M3 I = m3(c.inertia[i]);
-    const SV h = inertia_mul(c.mass[i], com, I, vi);
-    f[i] = inertia_mul(c.mass[i], com, I, ai) + crf(vi, h);
+    const V3 com = v3(c->com[i]);
+    const M3 I = m3(c->inertia[i]);
+    const SV h = inertia_mul(c->mass[i], com, I, vi);
+    f[i] = inertia_mul(c->mass[i], com, I, ai) + crf(vi, h);
     if (KEEP) { w.v[i] = vi; w.h[i] = h; w.vJ[i] = vJ; w.Xv[i] = Xv; w.Xa[i] = Xa; }
     vp = vi;
     ap = ai;
   }
   ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
-    tau[i] = dot(v3(c.axis[i]), f[i].ang);
+    tau[i] = dot(v3(c->axis[i]), f[i].ang);
     if (i > 0) f[i - 1] = f[i - 1] + force_act(k.liMi[i], f[i]);
     if (KEEP) w.F[i] = f[i];
   }
@@ -388,27 +400,27 @@ template <int NJ>
 struct Chain3D {
   // chain constants: the generic path reads the (large) table in place
   struct Consts {
-    const aslr_chain_t *c;
-    ASLR_DEV explicit Consts(const DevDesc &D) : c(&D.chain) {}
+    chain_cp c;
+    ASLR_DEV explicit Consts(const DevDesc &D) : c(chain_const(&D.chain)) {}
   };
-  const aslr_chain_t &c;
+  const chain_cp c;
   Kin<NJ> kin;
   RneaWs<NJ> ws;
   SE3d oMi[NJ];
-  ASLR_DEV explicit Chain3D(const Consts &cc) : c(*cc.c) {}
+  ASLR_DEV explicit Chain3D(const Consts &cc) : c(cc.c) {}
 
   ASLR_DEV void setup(const double *q) {
     ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
-      const M3 Rj = axis_angle(v3(c.axis[i]), q[i]);
-      kin.liMi[i].R = mul(m3(c.joint_R[i]), Rj);
-      kin.liMi[i].p = v3(c.joint_p[i]);
+      const M3 Rj = axis_angle(v3(c->axis[i]), q[i]);
+      kin.liMi[i].R = mul(m3(c->joint_R[i]), Rj);
+      kin.liMi[i].p = v3(c->joint_p[i]);
     }
   }
   // data.nle = RNEA(q, v, 0)
   ASLR_DEV void nle(const double *v, double *out) {
     double zero[NJ];
     ASLR_UNROLL for (int i = 0; i < NJ; ++i) zero[i] = 0.0;
-    rnea<NJ, false>(c, kin, v, zero, v3(c.gravity), out, ws);
+    rnea<NJ, false>(c, kin, v, zero, v3(c->gravity), out, ws);
   }
   // joint-space inertia: column j = RNEA(q, 0, e_j) without gravity; symmetrised like the Python
   // binding's data.M
@@ -419,12 +431,12 @@ struct Chain3D {
       ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
         if (i < j) { f[i] = sv_zero(); continue; }
         SV ai = (i == j) ? sv_zero() : motion_actinv(kin.liMi[i], ap);
-        if (i == j) ai.ang = v3(c.axis[i]);
-        f[i] = inertia_mul(c.mass[i], v3(c.com[i]), m3(c.inertia[i]), ai);
+        if (i == j) ai.ang = v3(c->axis[i]);
+        f[i] = inertia_mul(c->mass[i], v3(c->com[i]), m3(c->inertia[i]), ai);
         ap = ai;
       }
       ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
-        M[i][j] = dot(v3(c.axis[i]), f[i].ang);
+        M[i][j] = dot(v3(c->axis[i]), f[i].ang);
         if (i > 0) f[i - 1] = f[i - 1] + force_act(kin.liMi[i], f[i]);
       }
     }
@@ -439,10 +451,10 @@ struct Chain3D {
   // direction per column): dq[i][j] = dtau_i/dq_j, dv[i][j] = dtau_i/dv_j.
   ASLR_DEV void rnea_derivatives(const double *v, const double *a, double (&dq)[NJ][NJ], double (&dv)[NJ][NJ]) {
     double tau[NJ];
-    rnea<NJ, true>(c, kin, v, a, v3(c.gravity), tau, ws);
+    rnea<NJ, true>(c, kin, v, a, v3(c->gravity), tau, ws);
     ASLR_UNROLL for (int kind = 0; kind < 2; ++kind) {
       ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
-        const SV Sj = SV{V3{0, 0, 0}, v3(c.axis[j])};
+        const SV Sj = SV{V3{0, 0, 0}, v3(c->axis[j])};
         SV dvp = sv_zero(), dap = sv_zero();
         SV df[NJ];
         ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
@@ -454,15 +466,15 @@ struct Chain3D {
             else { dvi = Sj; dai = crm(ws.v[i], Sj); }
           }
           dai = dai + crm(dvi, ws.vJ[i]);
-          const V3 com = v3(c.com[i]);
-          const M3 I = m3(c.inertia[i]);
-          df[i] = inertia_mul(c.mass[i], com, I, dai) + crf(dvi, ws.h[i]) +
-                  crf(ws.v[i], inertia_mul(c.mass[i], com, I, dvi));
+          const V3 com = v3(c->com[i]);
+          const M3 I = m3(c->inertia[i]);
+          df[i] = inertia_mul(c->mass[i], com, I, dai) + crf(dvi, ws.h[i]) +
+                  crf(ws.v[i], inertia_mul(c->mass[i], com, I, dvi));
           dvp = dvi;
           dap = dai;
         }
         ASLR_UNROLL for (int i = NJ - 1; i >= 0; --i) {
-          const double val = dot(v3(c.axis[i]), df[i].ang);
+          const double val = dot(v3(c->axis[i]), df[i].ang);
           if (kind == 0) dq[i][j] = val; else dv[i][j] = val;
           if (i > 0) {
             df[i - 1] = df[i - 1] + force_act(kin.liMi[i], df[i]);
@@ -485,7 +497,7 @@ struct Chain3D {
     SE3d fMj;
     fMj.R = mulTN(oMf.R, oMi[j].R);
     fMj.p = mulT(oMf.R, oMi[j].p - oMf.p);
-    return motion_act(fMj, SV{V3{0, 0, 0}, v3(c.axis[j])});
+    return motion_act(fMj, SV{V3{0, 0, 0}, v3(c->axis[j])});
   }
 };
 

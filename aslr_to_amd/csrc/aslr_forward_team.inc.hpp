@@ -21,19 +21,6 @@
 
 namespace aslr {
 
-// The chain table is read-only for the lifetime of the problem.  Read through the constant address space, its
-// wave-uniform entries are fetched by scalar loads into SGPRs (s_load) instead of one vector load per lane that
-// the compiler must otherwise keep ordered with the kernel's global stores.
-typedef const aslr_chain_t __attribute__((address_space(4))) *chain_cp;
-typedef const double __attribute__((address_space(4))) *cdp;
-ASLR_DEV chain_cp chain_const(const aslr_chain_t *c) { return (chain_cp)c; }
-ASLR_DEV V3 v3(cdp p) { return V3{p[0], p[1], p[2]}; }
-ASLR_DEV M3 m3(cdp p) {
-  M3 m;
-  ASLR_UNROLL for (int i = 0; i < 9; ++i) m.a[i] = p[i];
-  return m;
-}
-
 // RNEA(q, v, a) of rnea<NJ, false>() with the joint rotations read from LDS (Rl[NJ][9], row-major)
 template <int NJ>
 ASLR_DEV void rnea_lds(chain_cp cp, const double *Rl, const double (&vv)[NJ], const double (&aa)[NJ], V3 grav,
