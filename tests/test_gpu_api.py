@@ -184,6 +184,44 @@ def test_full_batch_properties_and_batch_size_independence():
         assert (e.traj_f(_abi.TF_COST)[conv] <= cost_solver[conv] + 1e-9).all()
 
 
+def test_c5_shard_properties_and_batch_size_independence(oracle):
+    """The C5 shard (7-DoF SEA, nx = 28, 512 trajectories x 150 knots) through the block / team kernels:
+    invariants that need no oracle at full size, bit-identical per-trajectory results whatever the batch, and the
+    oracle on the first two trajectories."""
+    import torch
+    from aslr_to_amd.engine import Engine
+    sc = scenarios.talos_arm_sea(B=512, T=150, seed=0)
+    sp = scenarios.solver_params(sc, solver="SolverFDDP", maxiter=6)
+    e = Engine(scenarios.lower(sc))
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=0)
+    torch.cuda.synchronize()
+    X, U = e.region(_abi.R_XS).clone(), e.region(_abi.R_US).clone()
+    feas = e.traj_i(_abi.TI_FEASIBLE) != 0   # FDDP closes the initial gap x0 - xs[0] only with a full step
+    assert feas.any()
+    assert torch.equal(X[0][feas], torch.as_tensor(sc["x0"], device=X.device)[feas])
+    assert torch.isfinite(X).all() and torch.isfinite(U).all()
+    cost_solver, iters = e.traj_f(_abi.TF_COST).clone(), e.traj_i(_abi.TI_ITER).clone()
+    assert int(iters.min()) >= 1 and int(iters.max()) <= 6
+    e.calc()   # cost = sum of node costs on the solver's iterate
+    torch.cuda.synchronize()
+    assert ((e.region(_abi.R_COST).sum(dim=0) - cost_solver).abs() / (1 + cost_solver.abs())).max().item() < 1e-12
+    sub = scenarios.talos_arm_sea(B=512, T=150, seed=0)
+    sub["x0"], sub["frame_refs"] = sub["x0"][:2], sub["frame_refs"][:2]
+    low2 = scenarios.lower(sub)
+    e2 = Engine(low2)
+    e2.set_candidate(None, None)
+    e2.solve(sp, poll_every=0)
+    torch.cuda.synchronize()
+    assert torch.equal(e2.region(_abi.R_XS), X[:, :2]) and torch.equal(e2.region(_abi.R_US), U[:, :2])
+    assert torch.equal(e2.traj_i(_abi.TI_ITER), iters[:2])
+    ref = oracle.solve(low2, sp)
+    np.testing.assert_array_equal(iters[:2].cpu().numpy(), ref["traj_i"][_abi.TI_ITER])
+    scale = max(1.0, np.abs(ref["xs"]).max(), np.abs(ref["us"]).max())
+    assert np.abs(X[:, :2].cpu().numpy() - ref["xs"]).max() < 1e-6 * scale
+    assert np.abs(U[:, :2].cpu().numpy() - ref["us"]).max() < 1e-6 * scale
+
+
 def test_rollout_and_problem_calc_api():
     sc = scenarios.two_dof_sea(B=1, T=20)
     problem = crocoddyl.ShootingProblem(sc["x0"][0], sc["running"], sc["terminal"])
