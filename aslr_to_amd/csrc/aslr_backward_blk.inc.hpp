@@ -41,7 +41,14 @@ struct BwdBlk {
   static constexpr int LDS = even(sEnd);
 };
 
-template <int NX, int NU, bool GAPS>
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// MFMA: the two nx x nx x nx products (and P Fu) through v_mfma_f64_16x16x4_f64 -- 16 x 16 output tiles, wave w owns
+// rows 16w..16w+15 (lane l: operand row / column l & 15, contraction index l >> 4; results row (l >> 4) + 4 r,
+// column l & 15).  The instruction accumulates exactly like the k-ordered fma chain of the vector path
+// (tools/ubench/mfma_f64_layout.hip: 256 / 256 entries bit-equal), so both paths give the same bits.  It has the
+// vector unit's FP64 rate; what it saves is issue slots: 35 MFMAs per wave and knot replace 504 FMAs + 196 LDS reads.
+template <int NX, int NU, bool GAPS, bool MFMA>
 __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp) {
   using C = BwdBlk<NX, NU>;
   constexpr int REC = C::REC, NG = C::NG, NT = C::NT;
@@ -56,6 +63,8 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
   const int row[2] = {rr, rr + 16 < NX ? rr + 16 : NX - 1};               // rows of this thread (second clamped)
   const bool cell[2] = {g < NG, g < NG && rr + 16 < NX};                  // it owns entries (row[h], 4g..4g+3)
   const bool wave0 = tid < 64;
+  const int wv = tid >> 6, li = tid & 15, lk = (tid & 63) >> 4; // MFMA lane roles
+  constexpr int NKS = NX / 4;
   const int B = a.B, T = a.T, b = blockIdx.x;
   int32_t *TI = a.traj_i;
   double *TF = a.traj_f;
@@ -166,27 +175,52 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
       __syncthreads();
       if (t > 0) ASLR_BLK_PREFETCH(t - 1);
 
-      // ---- pass 1: C(r, 4g..) = sum_l P(r,l) Fx(l, 4g..)  [= A(4g.., r)],  (P Fu)(r, g) [= B(g, r)] ----
-      {
-        double c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, bu[2] = {0.0, 0.0};
-        const double2 *prow0 = reinterpret_cast<const double2 *>(PT + row[0] * NX);
-        const double2 *prow1 = reinterpret_cast<const double2 *>(PT + row[1] * NX);
-        _Pragma("unroll 2") for (int l = 0; l < NX; l += 2) {
-          const double2 p[2] = {prow0[l / 2], prow1[l / 2]};
-          const double2 *f0 = reinterpret_cast<const double2 *>(rec + C::oFx + l * NX + 4 * gc);
-          const double2 *f1 = reinterpret_cast<const double2 *>(rec + C::oFx + (l + 1) * NX + 4 * gc);
-          const double2 f0a = f0[0], f0b = f0[1], f1a = f1[0], f1b = f1[1];
-          const double u0 = rec[C::oFu + l * NU + gu], u1 = rec[C::oFu + (l + 1) * NU + gu];
-          ASLR_UNROLL for (int h = 0; h < 2; ++h) {
-            c[h][0] += p[h].x * f0a.x; c[h][1] += p[h].x * f0a.y; c[h][2] += p[h].x * f0b.x; c[h][3] += p[h].x * f0b.y;
-            bu[h] += p[h].x * u0;
-            c[h][0] += p[h].y * f1a.x; c[h][1] += p[h].y * f1a.y; c[h][2] += p[h].y * f1b.x; c[h][3] += p[h].y * f1b.y;
-            bu[h] += p[h].y * u1;
+      double bfx[2][MFMA ? NKS : 1]; // MFMA: the Fx operand fragments, reused by the second product
+      if constexpr (MFMA) {
+        // ---- pass 1 (MFMA): C = P Fx (row tile wv x column tiles 0, 1) and P Fu (column tile of Fu) ----
+        double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0, cu = c0;
+        const double *prow = PT + (16 * wv + li) * NX + lk; // (rows / columns >= nx read neighbouring LDS: unused results)
+        ASLR_UNROLL for (int ks = 0; ks < NKS; ++ks) {
+          const int k = 4 * ks + lk;
+          const double pa = prow[4 * ks];
+          bfx[0][ks] = rec[C::oFx + k * NX + li];
+          bfx[1][ks] = rec[C::oFx + k * NX + 16 + li];
+          const double bu = rec[C::oFu + k * NU + li];
+          c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, bfx[0][ks], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, bfx[1][ks], c1, 0, 0, 0);
+          cu = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, bu, cu, 0, 0, 0);
+        }
+        ASLR_UNROLL for (int q = 0; q < 4; ++q) {
+          const int rw = 16 * wv + lk + 4 * q;
+          if (rw < NX) {
+            AL[li * NX + rw] = c0[q];                          // A = C^T
+            if (16 + li < NX) AL[(16 + li) * NX + rw] = c1[q];
+            if (li < NU) BL[li * NX + rw] = cu[q];
           }
         }
-        ASLR_UNROLL for (int h = 0; h < 2; ++h) {
-          if (cell[h]) { ASLR_UNROLL for (int q = 0; q < 4; ++q) AL[(4 * g + q) * NX + row[h]] = c[h][q]; }
-          if (g < NU && (h == 0 || rr + 16 < NX)) BL[g * NX + row[h]] = bu[h];
+      } else {
+      // ---- pass 1: C(r, 4g..) = sum_l P(r,l) Fx(l, 4g..)  [= A(4g.., r)],  (P Fu)(r, g) [= B(g, r)] ----
+        {
+          double c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, bu[2] = {0.0, 0.0};
+          const double2 *prow0 = reinterpret_cast<const double2 *>(PT + row[0] * NX);
+          const double2 *prow1 = reinterpret_cast<const double2 *>(PT + row[1] * NX);
+          _Pragma("unroll 2") for (int l = 0; l < NX; l += 2) {
+            const double2 p[2] = {prow0[l / 2], prow1[l / 2]};
+            const double2 *f0 = reinterpret_cast<const double2 *>(rec + C::oFx + l * NX + 4 * gc);
+            const double2 *f1 = reinterpret_cast<const double2 *>(rec + C::oFx + (l + 1) * NX + 4 * gc);
+            const double2 f0a = f0[0], f0b = f0[1], f1a = f1[0], f1b = f1[1];
+            const double u0 = rec[C::oFu + l * NU + gu], u1 = rec[C::oFu + (l + 1) * NU + gu];
+            ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+              c[h][0] += p[h].x * f0a.x; c[h][1] += p[h].x * f0a.y; c[h][2] += p[h].x * f0b.x; c[h][3] += p[h].x * f0b.y;
+              bu[h] += p[h].x * u0;
+              c[h][0] += p[h].y * f1a.x; c[h][1] += p[h].y * f1a.y; c[h][2] += p[h].y * f1b.x; c[h][3] += p[h].y * f1b.y;
+              bu[h] += p[h].y * u1;
+            }
+          }
+          ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+            if (cell[h]) { ASLR_UNROLL for (int q = 0; q < 4; ++q) AL[(4 * g + q) * NX + row[h]] = c[h][q]; }
+            if (g < NU && (h == 0 || rr + 16 < NX)) BL[g * NX + row[h]] = bu[h];
+          }
         }
       }
       if (tid < NX) { // Qx = Lx + Fx^T Vx, Qu = Lu + Fu^T Vx (wave 0)
@@ -199,8 +233,22 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
         QuL[tid - NX] = rec[C::oLu + (tid - NX)] + s;
       }
       __syncthreads();
-      // ---- pass 2a: Qxx(r, 4g..) = Lxx + sum_l A(r,l) Fx(l, 4g..) ----
-      double qxx[2][4];
+      // ---- pass 2a: Qxx = Lxx + A Fx ----
+      double qxx[2][4]; // vector path: rows row[h], columns 4g..; MFMA path: column tile ct, rows 16 wv + lk + 4 q
+      if constexpr (MFMA) {
+        double4_t q0 = {0.0, 0.0, 0.0, 0.0}, q1 = q0;
+        const double *arow = AL + (16 * wv + li) * NX + lk;
+        ASLR_UNROLL for (int ks = 0; ks < NKS; ++ks) {
+          const double pa = arow[4 * ks];
+          q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, bfx[0][ks], q0, 0, 0, 0);
+          q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, bfx[1][ks], q1, 0, 0, 0);
+        }
+        ASLR_UNROLL for (int q = 0; q < 4; ++q) {
+          const int rw = 16 * wv + lk + 4 * q;
+          qxx[0][q] = rec[C::oLxx + rw * NX + li] + q0[q];
+          qxx[1][q] = rec[C::oLxx + rw * NX + 16 + li] + q1[q];
+        }
+      } else
       {
         double c[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
         const double2 *arow0 = reinterpret_cast<const double2 *>(AL + row[0] * NX);
@@ -289,27 +337,47 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
       if (FlagL[0]) { failed = true; break; } // block-uniform
       // ---- Vxx (unsymmetrised, state regularisation on the diagonal), K to HBM ----
       {
-        double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, k8[2][8];
-        ASLR_UNROLL for (int h = 0; h < 2; ++h) {
-          const double2 *qt = reinterpret_cast<const double2 *>(QuxT + row[h] * 8);
-          ASLR_UNROLL for (int c = 0; c < 8; c += 2) { const double2 v = qt[c / 2]; k8[h][c] = v.x; k8[h][c + 1] = v.y; }
-        }
-        ASLR_UNROLL for (int c = 0; c < NU; ++c) {
-          const double2 *kr = reinterpret_cast<const double2 *>(KL + c * NX + 4 * gc);
-          const double2 ka = kr[0], kb = kr[1];
-          ASLR_UNROLL for (int h = 0; h < 2; ++h) {
-            acc[h][0] += k8[h][c] * ka.x; acc[h][1] += k8[h][c] * ka.y; acc[h][2] += k8[h][c] * kb.x; acc[h][3] += k8[h][c] * kb.y;
+        if constexpr (MFMA) {
+          double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, k8[4][8];
+          ASLR_UNROLL for (int q = 0; q < 4; ++q) {
+            const int rw = 16 * wv + lk + 4 * q;
+            const double2 *qt = reinterpret_cast<const double2 *>(QuxT + (rw < NX ? rw : NX - 1) * 8);
+            ASLR_UNROLL for (int c = 0; c < 8; c += 2) { const double2 v = qt[c / 2]; k8[q][c] = v.x; k8[q][c + 1] = v.y; }
           }
-        }
-        ASLR_UNROLL for (int h = 0; h < 2; ++h) {
-          if (cell[h]) {
-            double2 *vo = reinterpret_cast<double2 *>(AL + row[h] * NX + 4 * g);
-            double2 va, vb;
-            va.x = (qxx[h][0] - acc[h][0]) + (row[h] == 4 * g + 0 ? xr : 0.0);
-            va.y = (qxx[h][1] - acc[h][1]) + (row[h] == 4 * g + 1 ? xr : 0.0);
-            vb.x = (qxx[h][2] - acc[h][2]) + (row[h] == 4 * g + 2 ? xr : 0.0);
-            vb.y = (qxx[h][3] - acc[h][3]) + (row[h] == 4 * g + 3 ? xr : 0.0);
-            vo[0] = va; vo[1] = vb;
+          const int cl[2] = {li, 16 + li < NX ? 16 + li : NX - 1};
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+            const double kc[2] = {KL[c * NX + cl[0]], KL[c * NX + cl[1]]};
+            ASLR_UNROLL for (int ct = 0; ct < 2; ++ct)
+              ASLR_UNROLL for (int q = 0; q < 4; ++q) acc[ct][q] += k8[q][c] * kc[ct];
+          }
+          ASLR_UNROLL for (int ct = 0; ct < 2; ++ct)
+            ASLR_UNROLL for (int q = 0; q < 4; ++q) {
+              const int rw = 16 * wv + lk + 4 * q, cw = 16 * ct + li;
+              if (rw < NX && cw < NX) AL[rw * NX + cw] = (qxx[ct][q] - acc[ct][q]) + (rw == cw ? xr : 0.0);
+            }
+        } else {
+          double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, k8[2][8];
+          ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+            const double2 *qt = reinterpret_cast<const double2 *>(QuxT + row[h] * 8);
+            ASLR_UNROLL for (int c = 0; c < 8; c += 2) { const double2 v = qt[c / 2]; k8[h][c] = v.x; k8[h][c + 1] = v.y; }
+          }
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+            const double2 *kr = reinterpret_cast<const double2 *>(KL + c * NX + 4 * gc);
+            const double2 ka = kr[0], kb = kr[1];
+            ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+              acc[h][0] += k8[h][c] * ka.x; acc[h][1] += k8[h][c] * ka.y; acc[h][2] += k8[h][c] * kb.x; acc[h][3] += k8[h][c] * kb.y;
+            }
+          }
+          ASLR_UNROLL for (int h = 0; h < 2; ++h) {
+            if (cell[h]) {
+              double2 *vo = reinterpret_cast<double2 *>(AL + row[h] * NX + 4 * g);
+              double2 va, vb;
+              va.x = (qxx[h][0] - acc[h][0]) + (row[h] == 4 * g + 0 ? xr : 0.0);
+              va.y = (qxx[h][1] - acc[h][1]) + (row[h] == 4 * g + 1 ? xr : 0.0);
+              vb.x = (qxx[h][2] - acc[h][2]) + (row[h] == 4 * g + 2 ? xr : 0.0);
+              vb.y = (qxx[h][3] - acc[h][3]) + (row[h] == 4 * g + 3 ? xr : 0.0);
+              vo[0] = va; vo[1] = vb;
+            }
           }
         }
         a.kgain[tb * NU * NX + tid] = KL[tid];
@@ -405,8 +473,17 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
 
 template <int NX, int NU>
 int launch_backward_blk(const KArgs &k, const SolverDev &sd, bool all_feasible, hipStream_t st) {
-  if (all_feasible) hipLaunchKernelGGL((backward_blk_kernel<NX, NU, false>), dim3(k.B), dim3(BwdBlk<NX, NU>::NT), 0, st, k, sd);
-  else hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true>), dim3(k.B), dim3(BwdBlk<NX, NU>::NT), 0, st, k, sd);
+  // ASLR_BLK_MFMA=0 selects the vector-FMA products (comparison runs; both paths give the same bits)
+  const char *e = getenv("ASLR_BLK_MFMA");
+  const bool mfma = e ? atoi(e) != 0 : true;
+  const dim3 grid(k.B), block(BwdBlk<NX, NU>::NT);
+  if (mfma) {
+    if (all_feasible) hipLaunchKernelGGL((backward_blk_kernel<NX, NU, false, true>), grid, block, 0, st, k, sd);
+    else hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true, true>), grid, block, 0, st, k, sd);
+  } else {
+    if (all_feasible) hipLaunchKernelGGL((backward_blk_kernel<NX, NU, false, false>), grid, block, 0, st, k, sd);
+    else hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true, false>), grid, block, 0, st, k, sd);
+  }
   HIP_TRY(hipGetLastError());
   return ASLR_OK;
 }
