@@ -830,6 +830,12 @@ void aslr_cpu_boxqp_hist_c0(long long *o32, int reset) {
   for (int i = 0; i < 32; ++i) o32[i] = g_qp_hist_c0[i / 16][i % 16];
   if (reset) memset(g_qp_hist_c0, 0, sizeof g_qp_hist_c0);
 }
+/* optional per-call log (serial runs): -2 = a trajectory's solve starts, -1 = a backward sweep starts, else the
+ * number of projected-Newton iterations of one BoxQP call (calls arrive knot T-1 ... 0) */
+static __thread int *g_qp_log; static __thread long g_qp_log_n, g_qp_log_cap;
+void aslr_cpu_boxqp_log(int *buf, long cap) { g_qp_log = buf; g_qp_log_cap = cap; g_qp_log_n = 0; }
+long aslr_cpu_boxqp_log_len(void) { return g_qp_log_n; }
+static void qp_log(int v) { if (g_qp_log && g_qp_log_n < g_qp_log_cap) g_qp_log[g_qp_log_n++] = v; }
 void aslr_cpu_boxqp_hist(long long *it16, long long *tr32, int reset) {
   for (int i = 0; i < 16; ++i) it16[i] = g_qp_hist_it[i];
   for (int i = 0; i < 32; ++i) tr32[i] = g_qp_hist_tr[i];
@@ -1004,6 +1010,7 @@ static void traj_calc_diff(traj_t *s) {
 /* SolverDDP::backwardPass + computeGains (B.1), SolverBoxDDP::computeGains (B.5).
  * Returns 1 on "backward_error". */
 static int traj_backward(traj_t *s) {
+  qp_log(-1);
   const int T = s->T, nx = s->nx, nu = s->nu;
   const aslr_solver_params_t *sp = s->sp;
   double *VxxT = s->Vxx + (size_t)T * nx * nx, *VxT = s->Vx + T * nx;
@@ -1079,6 +1086,7 @@ static int traj_backward(traj_t *s) {
       int r = aslr_cpu_boxqp(nu, Quu, Qu, lb, ub, xq, sp->boxqp_maxiter, sp->boxqp_th_acceptstep,
                              sp->boxqp_th_grad, sp->boxqp_reg, Hff_inv, fidx, &nf, cidx, &nc);
       if (r < 0) return 1;
+      qp_log(r + 10 * (nc > 0));
       memset(Quu_inv, 0, sizeof Quu_inv);
       for (int i = 0; i < nf; ++i)
         for (int j = 0; j < nf; ++j) Quu_inv[fidx[i] * nu + fidx[j]] = Hff_inv[i * nf + j];
@@ -1238,6 +1246,7 @@ static void reg_decrease(traj_t *s) {
 
 /* SolverDDP::solve / SolverFDDP::solve (B.2, B.4).  Returns 1 when converged. */
 static int traj_solve(traj_t *s) {
+  qp_log(-2);
   const aslr_solver_params_t *sp = s->sp;
   const int T = s->T, nx = s->nx, nu = s->nu;
   s->xreg = s->ureg = isnan(sp->reg_init) ? sp->reg_min : sp->reg_init;
