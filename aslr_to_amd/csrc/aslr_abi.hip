@@ -174,7 +174,6 @@ SolverDev to_dev(const aslr_solver_params_t *sp, int standalone, int store_v) {
   s.boxqp_maxiter = sp->boxqp_maxiter; s.boxqp_th_acceptstep = sp->boxqp_th_acceptstep;
   s.boxqp_th_grad = sp->boxqp_th_grad; s.boxqp_reg = sp->boxqp_reg;
   s.standalone = standalone; s.store_v = store_v;
-  { const char *e = getenv("ASLR_DEBUG"); s.debug = e ? atoi(e) : 0; }
   return s;
 }
 
@@ -206,7 +205,6 @@ int backward_hs(const aslr_problem *p) {
 int launch_backward(aslr_problem *p, const SolverDev &sd, hipStream_t st, bool all_feasible = false) {
   const int hs = backward_hs(p);
   const ModelLimits lim = make_limits(p);
-  { const char *e = getenv("ASLR_ASSUME_FEASIBLE"); if (e && atoi(e)) all_feasible = true; } // timing experiments only
   if (p->nx == 8) return launch_backward_nx8(p->k, p->nu, hs, sd, lim, all_feasible, st);
   if (p->nx == 28) return launch_backward_nx28(p->k, p->nu, hs, sd, lim, all_feasible, st);
   snprintf(g_err, sizeof g_err, "unsupported (nx=%d, nu=%d)", p->nx, p->nu);

@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       ASLR_UNROLL for (int r = 0; r < NX; ++r) fg[r] = pre_f[r];
       const int mi = pre_m;
       wave_sync();
-      if (t > 0 && !(sp.debug & 2)) ASLR_BWD_PREFETCH(t - 1);
+      if (t > 0) ASLR_BWD_PREFETCH(t - 1);
 
       // ---- step 1: A = Fx^T P (my rows of column jj), Bc = Fu^T P (column jj), Qx, Qu ----
       double Fxcol[NX], Fucol[NX];
@@ -399,13 +399,13 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         }
         if (!any_clamped && !plain_bad && sp.boxqp_reg == 0.0 && gnorm0 <= sp.boxqp_th_grad) {
           ASLR_UNROLL for (int c = 0; c < NU; ++c) kv[c] = -x0[c]; // (a)
-        } else if (interior || (sp.debug & 4)) {
+        } else if (interior) {
           // (b): kv, Kc already hold the result
         } else {
           double xq[NU];
           bool cm[NU];
           ASLR_UNROLL for (int c = 0; c < NU; ++c) { xq[c] = k0[c]; Kc[c] = Qux[c]; }
-          if (boxqp<NU>(Quu, qu, lb, ub, xq, cm, Kc, (sp.debug & 8) ? 1 : ((sp.debug & 16) ? 2 : sp.boxqp_maxiter), sp.boxqp_th_acceptstep, sp.boxqp_th_grad,
+          if (boxqp<NU>(Quu, qu, lb, ub, xq, cm, Kc, sp.boxqp_maxiter, sp.boxqp_th_acceptstep, sp.boxqp_th_grad,
                         sp.boxqp_reg)) failed = true;
           ASLR_UNROLL for (int c = 0; c < NU; ++c) {
             kv[c] = -xq[c];
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         ASLR_UNROLL for (int i = 0; i < RPL; ++i)
           if (row_ok(i)) VT[jj * NX + r0 + i] = (Qxx[i] - acc[i]) + oh_row[i] * xr;
       }
-      const bool st_ok = writer && need && !failed && !(sp.debug & 1);
+      const bool st_ok = writer && need && !failed;
       if (st_ok) {
         double *Kout = a.kgain + tb * NU * NX;
         ASLR_UNROLL for (int c = 0; c < NU; ++c) Kout[c * NX + jj] = Kc[c];

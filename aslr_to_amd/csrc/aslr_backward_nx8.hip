@@ -6,10 +6,6 @@ int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, con
   if (hs == 0) hs = k.B <= 8192 ? 2 : 1; // wider teams when the batch cannot fill the chip
   if (nu == 2) return hs == 2 ? launch_backward_t<8, 2, 2>(k, sd, lim, all_feasible, st) : launch_backward_t<8, 2, 1>(k, sd, lim, all_feasible, st);
   if (nu == 4) {
-    const char *e = getenv("ASLR_BWD_TPW");
-    const int tpw = e ? atoi(e) : 0;
-    if (hs == 2 && tpw == 2) return launch_backward_t<8, 4, 2, 2>(k, sd, lim, all_feasible, st);
-    if (hs == 2 && tpw == 1) return launch_backward_t<8, 4, 2, 1>(k, sd, lim, all_feasible, st);
     return hs == 2 ? launch_backward_t<8, 4, 2>(k, sd, lim, all_feasible, st) : launch_backward_t<8, 4, 1>(k, sd, lim, all_feasible, st);
   }
   snprintf(err_buf(), kErrLen, "backward: unsupported (nx=8, nu=%d)", nu);

@@ -50,7 +50,6 @@ struct SolverDev {
   double boxqp_th_acceptstep, boxqp_th_grad, boxqp_reg;
   int32_t standalone; // 1: API-level single pass (no retry, no solver-state updates)
   int32_t store_v;    // 1: write VX / VXX
-  int32_t debug;      // ASLR_DEBUG bits (timing experiments only): 1 no gain stores, 2 no record loads
 };
 
 // control limits of the (at most ASLR_MAX_MODELS) action models, passed by value so the backward loop
