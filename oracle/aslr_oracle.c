@@ -835,6 +835,10 @@ void aslr_cpu_boxqp_hist_c0(long long *o32, int reset) {
 static __thread int *g_qp_log; static __thread long g_qp_log_n, g_qp_log_cap;
 void aslr_cpu_boxqp_log(int *buf, long cap) { g_qp_log = buf; g_qp_log_cap = cap; g_qp_log_n = 0; }
 long aslr_cpu_boxqp_log_len(void) { return g_qp_log_n; }
+/* optional dump of whole QP instances (diagnostics): per call [H (n^2) | q | lb | ub | x0 | x* | iterations] */
+static __thread double *g_qp_dump; static __thread long g_qp_dump_n, g_qp_dump_cap;
+void aslr_cpu_boxqp_dump(double *buf, long cap) { g_qp_dump = buf; g_qp_dump_cap = cap; g_qp_dump_n = 0; }
+long aslr_cpu_boxqp_dump_len(void) { return g_qp_dump_n; }
 static void qp_log(int v) { if (g_qp_log && g_qp_log_n < g_qp_log_cap) g_qp_log[g_qp_log_n++] = v; }
 void aslr_cpu_boxqp_hist(long long *it16, long long *tr32, int reset) {
   for (int i = 0; i < 16; ++i) it16[i] = g_qp_hist_it[i];
@@ -1083,9 +1087,22 @@ static int traj_backward(traj_t *s) {
         ub[i] = m->u_ub[i] - s->us[t * nu + i];
         xq[i] = kk[i]; /* warm start at the stored k (sign as stored) */
       }
+      double x0_dump[NU];
+      memcpy(x0_dump, xq, sizeof(double) * nu);
       int r = aslr_cpu_boxqp(nu, Quu, Qu, lb, ub, xq, sp->boxqp_maxiter, sp->boxqp_th_acceptstep,
                              sp->boxqp_th_grad, sp->boxqp_reg, Hff_inv, fidx, &nf, cidx, &nc);
       if (r < 0) return 1;
+      if (g_qp_dump && g_qp_dump_n + nu * nu + 5 * nu + 1 <= g_qp_dump_cap) {
+        double *o = g_qp_dump + g_qp_dump_n;
+        memcpy(o, Quu, sizeof(double) * nu * nu); o += nu * nu;
+        memcpy(o, Qu, sizeof(double) * nu); o += nu;
+        memcpy(o, lb, sizeof(double) * nu); o += nu;
+        memcpy(o, ub, sizeof(double) * nu); o += nu;
+        memcpy(o, x0_dump, sizeof(double) * nu); o += nu;
+        memcpy(o, xq, sizeof(double) * nu); o += nu;
+        *o = (double)r;
+        g_qp_dump_n += nu * nu + 5 * nu + 1;
+      }
       qp_log(r + 10 * (nc > 0));
       memset(Quu_inv, 0, sizeof Quu_inv);
       for (int i = 0; i < nf; ++i)
