@@ -50,6 +50,9 @@ struct aslr_problem {
   int32_t *h_done; // pinned staging for count_active
   hipEvent_t ev[4];
   bool have_ev;
+  // model-only chunks of the DERIV records (cost-weight diagonals): const_ok = the cost stacks allow skipping them,
+  // const_written = a sweep that evaluated every knot of every trajectory has put them in place
+  bool const_ok, const_written;
 };
 
 namespace {
@@ -178,7 +181,11 @@ SolverDev to_dev(const aslr_solver_params_t *sp, int standalone, int store_v) {
 }
 
 // ---- launch helpers: dispatch to the per-size translation units ----
-int launch_calc(aslr_problem *p, bool diff, int mode, double th_gaptol, hipStream_t st) {
+int launch_calc(aslr_problem *p, bool diff, int mode, double th_gaptol, hipStream_t st, bool all_computed = false) {
+  if (diff && p->const_ok && !(mode & kModeNoCompute)) {
+    if (p->const_written) mode |= kModeSkipConst;
+    else if (all_computed) p->const_written = true; // this launch writes them
+  }
   if (p->nj == 2) return launch_calc_nj2(p->k, p->dam, diff, mode, th_gaptol, st);
   if (p->nj == 7) return launch_calc_nj7(p->k, p->dam, diff, mode, th_gaptol, st);
   snprintf(g_err, sizeof g_err, "unsupported nj=%d", p->nj);
@@ -290,6 +297,11 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   p->desc = *desc;
   p->desc.node_model = nullptr; p->desc.x0 = nullptr; p->desc.frame_ref = nullptr;
   p->nj = nj; p->nx = nx; p->nu = nu; p->dam = dam; p->rec = rec_len_c(nx, nu);
+  p->const_written = false;
+  p->const_ok = true; // every cost type but the pendulum cost has a knot-independent diagonal Hessian outside Lqq
+  for (int i = 0; i < desc->nmodels; ++i)
+    for (int c = 0; c < desc->models[i].ncosts; ++c)
+      if (desc->models[i].costs[c].type == ASLR_COST_PENDULUM) p->const_ok = false;
   int64_t total;
   carve(desc, nx, nu, p->regions, &total);
   if (!workspace || workspace_bytes < total || (reinterpret_cast<uintptr_t>(workspace) & 255u)) {
@@ -374,7 +386,7 @@ int aslr_calc(aslr_problem_t *p, void *stream) {
 
 int aslr_calc_diff(aslr_problem_t *p, void *stream) {
   if (!p) return ASLR_E_INVALID;
-  return launch_calc(p, true, 0, -1.0, static_cast<hipStream_t>(stream));
+  return launch_calc(p, true, 0, -1.0, static_cast<hipStream_t>(stream), true);
 }
 
 int aslr_backward_pass(aslr_problem_t *p, const aslr_solver_params_t *sp, void *stream) {
@@ -396,7 +408,7 @@ int aslr_iterate(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t firs
     HIP_TRY(hipGetLastError());
   }
   const SolverDev sd = to_dev(sp, 0, 0);
-  int rc = launch_calc(p, true, kModeCommit | kModeSolver, sp->th_gaptol, st);
+  int rc = launch_calc(p, true, kModeCommit | kModeSolver, sp->th_gaptol, st, first != 0); // the first sweep evaluates all
   if (rc) return rc;
   rc = launch_backward(p, sd, st);
   if (rc) return rc;
@@ -417,7 +429,7 @@ int aslr_iterate_timed(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_
   }
   const SolverDev sd = to_dev(sp, 0, 0);
   HIP_TRY(hipEventRecord(p->ev[0], st));
-  int rc = launch_calc(p, true, kModeCommit | kModeSolver, sp->th_gaptol, st);
+  int rc = launch_calc(p, true, kModeCommit | kModeSolver, sp->th_gaptol, st, first != 0); // the first sweep evaluates all
   if (rc) return rc;
   HIP_TRY(hipEventRecord(p->ev[1], st));
   rc = launch_backward(p, sd, st);

@@ -65,6 +65,7 @@ __device__ __forceinline__ bool is_bad(double v) { return isnan(v) || isinf(v) |
 constexpr int kModeCommit = 1;    // copy the accepted candidate XS_TRY/US_TRY[acc] into XS/US
 constexpr int kModeSolver = 2;    // honour RECALC/DONE flags and compute gaps
 constexpr int kModeNoCompute = 4;
+constexpr int kModeSkipConst = 8; // record chunks that depend on the model only are in place already: do not rewrite them
 
 // launchers, one translation unit per (kernel family, size)
 int launch_calc_nj2(const KArgs &k, int dam, bool diff, int mode, double th_gaptol, hipStream_t st);

@@ -70,6 +70,17 @@ def test_calc_and_calcdiff_match_oracle(oracle, name, kw):
     _sync()
     assert _relerr(_np(e.region(_abi.R_XNEXT)), xnext) < 1e-11
     assert _relerr(_np(e.region(_abi.R_COST)), cost) < 1e-11
+    # a second sweep at another point: the record chunks that are structural zeros or depend on the model only are
+    # not rewritten by it (DERIV was zero-filled at creation, the first sweep put the cost-weight diagonals in place)
+    xs2, us2 = _random_candidate(low, 5)
+    e.region(_abi.R_XS).copy_(torch.as_tensor(xs2))
+    e.region(_abi.R_US).copy_(torch.as_tensor(us2))
+    e.calc_diff()
+    _sync()
+    _, _, deriv2 = oracle.calc_diff(low, xs2, us2)
+    assert np.abs(deriv2 - deriv).max() > 1e-3        # the point really changed
+    err = _relerr(_np(e.region(_abi.R_DERIV)), deriv2)
+    assert err < 1e-9, "DERIV record mismatch on the second sweep %g" % err
 
 
 def _backward_inputs(oracle, low, seed):
