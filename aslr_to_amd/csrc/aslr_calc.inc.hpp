@@ -1,4 +1,4 @@
-// aslr_calc.inc.hpp -- calc / calcDiff / dam_eval kernels (see aslr_kernels.md for the design)
+// aslr_calc.inc.hpp -- calc / calcDiff / dam_eval kernels (design: DESIGN.md section 4.1)
 #pragma once
 #include "aslr_common.hpp"
 
