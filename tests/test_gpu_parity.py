@@ -224,6 +224,37 @@ def test_vsa_modified_example_first_iterations_match_oracle(oracle):
     assert (_np(e.region(_abi.R_US))[..., 2:] >= 0.002).all()   # the stiffness bound holds
 
 
+def test_three_action_models_along_the_horizon_match_oracle(oracle):
+    """A horizon made of three distinct action models (control limits and dt = 1e-2 on the first 15 knots, no limits,
+    dt = 5e-3 and a heavier control regulariser on the next 15, then the terminal model): the per-node model switch
+    of every kernel (constants reloaded mid-sweep, limits per node) against the oracle."""
+    sc = scenarios.two_dof_vsa_boxddp(B=6, T=30)
+    import copy
+    rm = sc["running"][0]
+    memo = {id(rm.state): rm.state, id(rm.state.pinocchio): rm.state.pinocchio}   # same robot model object
+    other = copy.deepcopy(rm, memo)
+    other.dt = 5e-3
+    other.u_lb = np.full(4, -np.inf)
+    other.u_ub = np.full(4, np.inf)
+    other.differential.costs.costs["uReg"].weight = 0.5
+    sc["running"] = sc["running"][:15] + [other] * 15
+    low = scenarios.lower(sc)
+    assert low.desc.nmodels == 3 and list(low.node_model) == [0] * 15 + [1] * 15 + [2]
+    sp = scenarios.solver_params(sc, maxiter=40)
+    ref = oracle.solve(low, sp)
+    e = _engine(low)
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=4)
+    _sync()
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER])
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)), ref["traj_i"][_abi.TI_STATUS])
+    scale = max(1.0, np.abs(ref["xs"]).max(), np.abs(ref["us"]).max())
+    assert np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max() < 1e-6 * scale
+    assert np.abs(_np(e.region(_abi.R_US)) - ref["us"]).max() < 1e-6 * scale
+    U = _np(e.region(_abi.R_US))
+    assert (U[:15, :, 2:] >= 0.0).all()          # the first model's stiffness bound holds on its knots
+
+
 def _indefinite_sea(B, T, cost_name, weight):
     """SEA problem with one NEGATIVE cost weight: Quu / Vxx turn indefinite, so backward passes fail
     (Cholesky "backward_error" -> increaseRegularization -> retry without recalc) and the
