@@ -492,6 +492,21 @@ struct Chain3D {
     ASLR_UNROLL for (int i = 1; i < NJ; ++i) if (i == fj) r = oMi[i];
     return r;
   }
+  // world placement of joint fj alone (cost-only evaluations): the same products in the same order as setup() +
+  // joint_world(), as a running product -- no per-joint arrays (they cost 3.4 KB of scratch per lane at nj = 7)
+  ASLR_DEV static SE3d world_of(const Consts &cc, const double *q, int fj) {
+    const chain_cp c = cc.c;
+    SE3d r;
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+      if (i <= fj) { // wave-uniform (fj is a constant of the cost)
+        SE3d li;
+        li.R = mul(m3(c->joint_R[i]), axis_angle(v3(c->axis[i]), q[i]));
+        li.p = v3(c->joint_p[i]);
+        if (i == 0) r = li; else r = se3_mul(r, li);
+      }
+    }
+    return r;
+  }
   // LOCAL frame Jacobian column j: (oMf^-1 oMj).act(S_j)
   ASLR_DEV SV jac_col(int j, const SE3d &oMf) const {
     SE3d fMj;
@@ -654,6 +669,11 @@ struct ChainPlanar {
     r.R.a[6] = 0.0; r.R.a[7] = 0.0; r.R.a[8] = 1.0;
     r.p = V3{x, y, z};
     return r;
+  }
+  ASLR_DEV static SE3d world_of(const Consts &cc, const double *q, int fj) {
+    ChainPlanar ch(cc);
+    ch.setup(q);
+    return ch.joint_world(fj);
   }
   ASLR_DEV SV jac_col(int j, const SE3d &oMf) const {
     // joint j turns the frame about the world z axis through (Px[j], Py[j])
@@ -843,7 +863,8 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
   ASLR_UNROLL for (int i = 0; i < NJ; ++i) { q[i] = x[i]; v[i] = x[2 * NJ + i]; dqm[i] = x[i] - x[NJ + i]; }
 
   CH ch(cc);
-  ch.setup(q);
+  constexpr bool NEEDCH = DYN || DIFF; // a cost-only evaluation takes the lean forward kinematics below
+  if constexpr (NEEDCH) ch.setup(q);
 
   if (DYN) {
     // stiffness / coupling torque / motor torque
@@ -951,7 +972,8 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
     const double w = ct.weight;
     if (ct.type == ASLR_COST_FRAME_PLACEMENT) {
       const int fj = ct.frame_joint;
-      const SE3d oMj = ch.joint_world(fj);
+      SE3d oMj;
+      if constexpr (NEEDCH) oMj = ch.joint_world(fj); else oMj = CH::world_of(cc, q, fj);
       const SE3d F = SE3d{m3(ct.frame_R), v3(ct.frame_p)};
       const SE3d oMf = se3_mul(oMj, F);
       const double *ref = frame_ref ? frame_ref : ct.ref;
