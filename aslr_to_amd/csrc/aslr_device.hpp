@@ -492,6 +492,21 @@ struct Chain3D {
     ASLR_UNROLL for (int i = 1; i < NJ; ++i) if (i == fj) r = oMi[i];
     return r;
   }
+  // world placements of all joints without keeping the parent-to-child transforms (cost derivatives when the
+  // dynamics were evaluated elsewhere): same products, same order as setup() + joint_world()
+  ASLR_DEV void setup_world(const double *q) {
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+      SE3d li;
+      li.R = mul(m3(c->joint_R[i]), axis_angle(v3(c->axis[i]), q[i]));
+      li.p = v3(c->joint_p[i]);
+      if (i == 0) oMi[0] = li; else oMi[i] = se3_mul(oMi[i - 1], li);
+    }
+  }
+  ASLR_DEV SE3d joint_world_ready(int fj) const {
+    SE3d r = oMi[0];
+    ASLR_UNROLL for (int i = 1; i < NJ; ++i) if (i == fj) r = oMi[i];
+    return r;
+  }
   // world placement of joint fj alone (cost-only evaluations): the same products in the same order as setup() +
   // joint_world(), as a running product -- no per-joint arrays (they cost 3.4 KB of scratch per lane at nj = 7)
   ASLR_DEV static SE3d world_of(const Consts &cc, const double *q, int fj) {
@@ -670,6 +685,8 @@ struct ChainPlanar {
     r.p = V3{x, y, z};
     return r;
   }
+  ASLR_DEV void setup_world(const double *q) { setup(q); }
+  ASLR_DEV SE3d joint_world_ready(int fj) { return joint_world(fj); }
   ASLR_DEV static SE3d world_of(const Consts &cc, const double *q, int fj) {
     ChainPlanar ch(cc);
     ch.setup(q);
@@ -864,7 +881,8 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
 
   CH ch(cc);
   constexpr bool NEEDCH = DYN || DIFF; // a cost-only evaluation takes the lean forward kinematics below
-  if constexpr (NEEDCH) ch.setup(q);
+  constexpr bool WORLDONLY = DIFF && !DYN; // cost derivatives only: joint placements, no parent-to-child transforms
+  if constexpr (WORLDONLY) ch.setup_world(q); else if constexpr (NEEDCH) ch.setup(q);
 
   if (DYN) {
     // stiffness / coupling torque / motor torque
@@ -973,7 +991,9 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
     if (ct.type == ASLR_COST_FRAME_PLACEMENT) {
       const int fj = ct.frame_joint;
       SE3d oMj;
-      if constexpr (NEEDCH) oMj = ch.joint_world(fj); else oMj = CH::world_of(cc, q, fj);
+      if constexpr (WORLDONLY) oMj = ch.joint_world_ready(fj);
+      else if constexpr (NEEDCH) oMj = ch.joint_world(fj);
+      else oMj = CH::world_of(cc, q, fj);
       const SE3d F = SE3d{m3(ct.frame_R), v3(ct.frame_p)};
       const SE3d oMf = se3_mul(oMj, F);
       const double *ref = frame_ref ? frame_ref : ct.ref;
