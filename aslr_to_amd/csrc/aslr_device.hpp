@@ -57,6 +57,43 @@ ASLR_DEV void sincos_fast(double x, double *sn, double *cs) {
   *cs = ((n + 1) & 2) ? -c0 : c0;
 }
 
+// sincos_fast with its 16 constants passed in (VGPR-resident copies made once per kernel by SinCosK): in a loop over
+// knots the compiler otherwise re-materialises every 64-bit literal with two scalar moves per use and iteration,
+// 64 SALU instructions per knot of the planar rollout -- which runs at the one-instruction-per-8-cycles issue limit.
+struct SinCosK {
+  double k[16];
+  // opaque = true: VGPR-resident copies (kernels that loop over knots); false: plain literals, folded as before
+  ASLR_DEV explicit SinCosK(bool opaque) {
+    const double v[16] = {6.36619772367581382433e-01, 1.57079632673412561417e+00, 6.07710050650619224932e-11,
+                          8.33333333332248946124e-03, -1.98412698298579493134e-04, 2.75573137070700676789e-06,
+                          -2.50507602534068634195e-08, 1.58969099521155010221e-10, -1.66666666666666324348e-01,
+                          4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+                          -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11, 0.5};
+    ASLR_UNROLL for (int i = 0; i < 16; ++i) {
+      double c = v[i];
+      if (opaque) asm volatile("" : "+v"(c)); // an opaque register value from here on
+      k[i] = c;
+    }
+  }
+};
+ASLR_DEV void sincos_fast(const SinCosK &K, double x, double *sn, double *cs) {
+  if (!(fabs(x) < 1.0e5)) { sincos(x, sn, cs); return; }
+  const double *k = K.k;
+  const double fn = rint(x * k[0]);
+  const double r = fma(-fn, k[1], x);
+  const double y = r - fn * k[2];
+  const double z = y * y;
+  const double rs = k[3] + z * (k[4] + z * (k[5] + z * (k[6] + z * k[7])));
+  const double ks = y + (z * y) * (k[8] + z * rs);
+  const double rc = z * (k[9] + z * (k[10] + z * (k[11] + z * (k[12] + z * (k[13] + z * k[14])))));
+  const double hz = k[15] * z, w = 1.0 - hz;
+  const double kc = w + (((1.0 - w) - hz) + z * rc);
+  const int n = (int)fn & 3;
+  const double s0 = (n & 1) ? kc : ks, c0 = (n & 1) ? ks : kc;
+  *sn = (n & 2) ? -s0 : s0;
+  *cs = ((n + 1) & 2) ? -c0 : c0;
+}
+
 // Device-side model: the ABI struct plus host-precomputed inverse of the motor inertia.
 struct DevModel {
   aslr_model_t m;
@@ -401,7 +438,7 @@ struct Chain3D {
   // chain constants: the generic path reads the (large) table in place
   struct Consts {
     chain_cp c;
-    ASLR_DEV explicit Consts(const DevDesc &D) : c(chain_const(&D.chain)) {}
+    ASLR_DEV explicit Consts(const DevDesc &D, bool = false) : c(chain_const(&D.chain)) {}
   };
   const chain_cp c;
   Kin<NJ> kin;
@@ -562,7 +599,8 @@ struct ChainPlanar {
   // evaluates many knots per lane does not re-fetch them every knot
   struct Consts {
     double gx, gy, cphi[NJ], sphi[NJ], px[NJ], py[NJ], pz[NJ], m[NJ], cx[NJ], cy[NJ], izz[NJ];
-    ASLR_DEV explicit Consts(const DevDesc &D) {
+    SinCosK sck;
+    ASLR_DEV explicit Consts(const DevDesc &D, bool loop_kernel = false) : sck(loop_kernel) {
       const PlanarChain &p = D.planar;
       gx = p.gx; gy = p.gy;
       ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
@@ -581,7 +619,7 @@ struct ChainPlanar {
   ASLR_DEV void setup(const double *q) {
     ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
       double s, c;
-      sincos_fast(q[i], &s, &c);
+      sincos_fast(pc.sck, q[i], &s, &c);
       // Rz(phi_i) Rz(q_i)
       X[i] = PX{pc.cphi[i] * c - pc.sphi[i] * s, pc.sphi[i] * c + pc.cphi[i] * s, pc.px[i], pc.py[i]};
     }

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
     const double *x0 = a.x0 + (size_t)b * NX;
     ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = x0[i];
   }
-  const typename CH::Consts cc(D);
+  const typename CH::Consts cc(D, true); // (true: this kernel loops over knots -- sin / cos constants in registers)
   ModelRegs<NJ, NU> mr;
   int m_loaded = -1;
   // Per-knot inputs shared by the step lengths of a trajectory -- [K | xs | us | k | gaps | Vxx f] -- are loaded
