@@ -319,6 +319,23 @@ class SolverDDP(object):
         v = e.region(rid)
         return [g for g in v[:, 0].cpu().numpy()] if self._single() else v.transpose(0, 1)
 
+    def _value(self, rid):
+        """Vx / Vxx are not kept by the solve loop (212 MB per 4096-trajectory shard, written for nobody): they are
+        recomputed here by one stand-alone backward pass on the CURRENT iterate and regularisation (Crocoddyl
+        holds those of its last iteration's backward pass, i.e. one step earlier); K, k, Qu are left untouched."""
+        import torch
+        e = self.problem.engine
+        keep = [(r, e.region(r).clone()) for r in (_abi.R_KGAIN, _abi.R_KFF, _abi.R_QU)]
+        e.calc_diff()
+        e.backward_pass(self._sp)
+        torch.cuda.synchronize(e.device)
+        v = e.region(rid).clone()
+        for r, t in keep:
+            e.region(r).copy_(t)
+        return [g for g in v[:, 0].cpu().numpy()] if self._single() else v.transpose(0, 1)
+
+    Vx = property(lambda s: s._value(_abi.R_VX))
+    Vxx = property(lambda s: s._value(_abi.R_VXX))
     K = property(lambda s: s._gain(_abi.R_KGAIN))
     k = property(lambda s: s._gain(_abi.R_KFF))
     Qu = property(lambda s: s._gain(_abi.R_QU))

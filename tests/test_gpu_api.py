@@ -222,6 +222,26 @@ def test_c5_shard_properties_and_batch_size_independence(oracle):
     assert np.abs(U[:, :2].cpu().numpy() - ref["us"]).max() < 1e-6 * scale
 
 
+def test_solver_value_function_getters():
+    """solver.Vx / solver.Vxx: terminal values are the terminal cost's Lx / Lxx (+ x_reg on the
+    diagonal), Vxx is symmetric, and asking for them leaves the gains alone."""
+    sc = scenarios.two_dof_sea(B=1, T=12)
+    problem = crocoddyl.ShootingProblem(sc["x0"][0], sc["running"], sc["terminal"])
+    solver = crocoddyl.SolverDDP(problem)
+    solver.th_stop = 1e-7
+    solver.solve([], [], 30)
+    K0 = [k.copy() for k in solver.K]
+    Vxx, Vx = solver.Vxx, solver.Vx
+    assert len(Vxx) == 13 and Vxx[0].shape == (8, 8) and Vx[0].shape == (8,)
+    for V in Vxx:
+        np.testing.assert_allclose(V, V.T, atol=1e-12)
+    tdata = problem.terminalData
+    np.testing.assert_allclose(Vxx[-1], tdata.Lxx + solver.x_reg * np.eye(8), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(Vx[-1], tdata.Lx, rtol=1e-12, atol=1e-12)
+    for a, b in zip(K0, solver.K):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_rollout_and_problem_calc_api():
     sc = scenarios.two_dof_sea(B=1, T=20)
     problem = crocoddyl.ShootingProblem(sc["x0"][0], sc["running"], sc["terminal"])
