@@ -167,10 +167,9 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
 
 // ShootingProblem.quasiStatic (examples/two_dof_sea.py:78): Crocoddyl's base-class
 // Gauss-Newton per running node, u = 0; repeat { calc, calcDiff; du = -pinv(Fu) (xnext - x); u += du }
-// until |du| <= tol or maxiter.  One lane per (trajectory, node).  pinv(Fu) = (Fu^T Fu)^-1 Fu^T, valid for
-// the full-column-rank Fu of the SEA models (the only example whose quasi-static result is used); a
-// rank-deficient Fu^T Fu (e.g. VSA at q_l = q_m, where the stiffness columns vanish) leaves u untouched
-// and reports -1 iterations for that node.
+// until |du| <= tol or maxiter.  One lane per (trajectory, node).  pinv(Fu) acts through the normal equations
+// and a thresholded eigen-decomposition (pinv_normal_solve), so a rank-deficient Fu -- VSA at q_l = q_m, where
+// the stiffness columns vanish -- gets the minimum-norm update Crocoddyl's SVD pseudo-inverse gives.
 template <int NJ, int DAM, bool PLANAR>
 __global__ void __launch_bounds__(64) quasi_static_kernel(KArgs a, int maxiter, double tol, int32_t *iters_out) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu, NV = 2 * NJ;
@@ -189,7 +188,6 @@ __global__ void __launch_bounds__(64) quasi_static_kernel(KArgs a, int maxiter, 
   ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = a.xs[tb * NX + i];
   ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = 0.0;
   int it = 0;
-  bool singular = false;
   for (; it < maxiter; ++it) {
     double xnext[NX], c;
     KnotDiff<NJ, NU> kd;
@@ -215,17 +213,17 @@ __global__ void __launch_bounds__(64) quasi_static_kernel(KArgs a, int maxiter, 
         A[i][j] = s2;
       }
     }
-    double rinv[NU];
-    if (chol_r<NU>(A, rinv)) { singular = true; break; }
-    chol_solve_r<NU>(A, rinv, rhs);
+    {
+      double g[NU];
+      ASLR_UNROLL for (int i = 0; i < NU; ++i) g[i] = rhs[i];
+      pinv_normal_solve<NU>(NX, A, g, rhs);
+    }
     double nrm = 0.0;
     ASLR_UNROLL for (int i = 0; i < NU; ++i) { u[i] += rhs[i]; nrm += rhs[i] * rhs[i]; }
     if (sqrt(nrm) <= tol) break;
   }
-  if (!singular) {
-    ASLR_UNROLL for (int i = 0; i < NU; ++i) a.us[tb * NU + i] = u[i];
-  }
-  if (iters_out) iters_out[tb] = singular ? -1 : it;
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) a.us[tb * NU + i] = u[i];
+  if (iters_out) iters_out[tb] = it;
 }
 
 // DAM-level evaluation of arbitrary points (aslr_dam_eval): dense continuous blocks, one lane per point

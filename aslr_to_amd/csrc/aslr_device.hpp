@@ -872,6 +872,55 @@ ASLR_DEV void spd_inverse_fast(const double (&A)[N][N], double (&Ainv)[N][N]) {
   }
 }
 
+// x = pinv(F) b from A = F^T F and g = F^T b (thresholded Jacobi eigen-decomposition; the oracle's
+// pinv_normal_solve, same operation order): Crocoddyl's pseudoInverse for quasiStatic, rank-deficient F included
+template <int N>
+ASLR_DEV void pinv_normal_solve(int rows, double (&A)[N][N], const double (&g)[N], double (&x)[N]) {
+  double V[N][N];
+  ASLR_UNROLL for (int i = 0; i < N; ++i)
+    ASLR_UNROLL for (int j = 0; j < N; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 8; ++sweep) {
+    ASLR_UNROLL for (int p = 0; p < N - 1; ++p)
+      ASLR_UNROLL for (int q = p + 1; q < N; ++q) {
+        const double apq = A[p][q];
+        if (apq != 0.0) {
+          const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+          const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+          ASLR_UNROLL for (int k = 0; k < N; ++k) {
+            const double akp = A[k][p], akq = A[k][q];
+            A[k][p] = c * akp - sn * akq;
+            A[k][q] = sn * akp + c * akq;
+          }
+          ASLR_UNROLL for (int k = 0; k < N; ++k) {
+            const double apk = A[p][k], aqk = A[q][k];
+            A[p][k] = c * apk - sn * aqk;
+            A[q][k] = sn * apk + c * aqk;
+          }
+          ASLR_UNROLL for (int k = 0; k < N; ++k) {
+            const double vkp = V[k][p], vkq = V[k][q];
+            V[k][p] = c * vkp - sn * vkq;
+            V[k][q] = sn * vkp + c * vkq;
+          }
+        }
+      }
+  }
+  double lmax = 0.0;
+  ASLR_UNROLL for (int i = 0; i < N; ++i) lmax = fmax(lmax, fabs(A[i][i]));
+  const double thr = 2.220446049250313e-16 * (double)(rows > N ? rows : N) * lmax;
+  double y[N];
+  ASLR_UNROLL for (int i = 0; i < N; ++i) {
+    double a = 0.0;
+    ASLR_UNROLL for (int k = 0; k < N; ++k) a += V[k][i] * g[k];
+    y[i] = A[i][i] > thr ? a / A[i][i] : 0.0;
+  }
+  ASLR_UNROLL for (int k = 0; k < N; ++k) {
+    double a = 0.0;
+    ASLR_UNROLL for (int i = 0; i < N; ++i) a += V[k][i] * y[i];
+    x[k] = a;
+  }
+}
+
 // dynamics constants of one action model held in registers
 template <int NJ, int NU>
 struct ModelRegs {

@@ -1451,6 +1451,56 @@ int aslr_cpu_forward_pass(const aslr_problem_desc_t *d, const aslr_solver_params
 }
 
 /* ActionModelAbstract::quasiStatic: Gauss-Newton on u with pinv(Fu) */
+/* x = pinv(F) b for the SYMMETRIC positive semi-definite normal matrix A = F^T F (n <= NU) and g = F^T b:
+ * cyclic Jacobi eigen-decomposition A = V diag(lam) V^T (8 sweeps), x = V diag(lam_i > thr ? 1 / lam_i : 0) V^T g
+ * with thr = eps * max(rows, n) * lam_max.  This is Crocoddyl's pseudoInverse (JacobiSVD of F with its singular
+ * values cut at eps * max(rows, n) * sigma_max) restated on the normal equations: exact zero columns of F (the
+ * VSA stiffness columns at q_l = q_m) give exact zero eigenvalues and are dropped, like there. */
+static void pinv_normal_solve(int n, int rows, const double *A_in, const double *g, double *x) {
+  double A[NU * NU], V[NU * NU];
+  memcpy(A, A_in, sizeof(double) * n * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 8; ++sweep)
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[p * n + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < n; ++k) { /* columns p, q */
+          const double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - sn * akq;
+          A[k * n + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) { /* rows p, q */
+          const double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - sn * aqk;
+          A[q * n + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - sn * vkq;
+          V[k * n + q] = sn * vkp + c * vkq;
+        }
+      }
+  double lmax = 0.0;
+  for (int i = 0; i < n; ++i) lmax = fmax(lmax, fabs(A[i * n + i]));
+  const double thr = 2.220446049250313e-16 * (double)(rows > n ? rows : n) * lmax;
+  double y[NU];
+  for (int i = 0; i < n; ++i) {
+    double a = 0.0;
+    for (int k = 0; k < n; ++k) a += V[k * n + i] * g[k];
+    y[i] = A[i * n + i] > thr ? a / A[i * n + i] : 0.0;
+  }
+  for (int k = 0; k < n; ++k) {
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) a += V[k * n + i] * y[i];
+    x[k] = a;
+  }
+}
+
 int aslr_cpu_quasi_static(const aslr_problem_desc_t *d, int mi, const double *frame_ref,
                           const double *x, double *u, int maxiter, double tol) {
   const aslr_model_t *m = &d->models[mi];
@@ -1461,7 +1511,7 @@ int aslr_cpu_quasi_static(const aslr_problem_desc_t *d, int mi, const double *fr
   for (it = 0; it < maxiter; ++it) {
     aslr_cpu_knot(&d->chain, m, frame_ref, x, u, xnext, &cost, rec);
     const double *Fu = rec + nx * nx;
-    /* du = -pinv(Fu) dx = -(Fu^T Fu)^-1 Fu^T dx  (Fu has full column rank here) */
+    /* du = -pinv(Fu) dx through the normal equations and a thresholded eigen-decomposition (rank-deficient Fu too) */
     double A[NU * NU], rhs[NU];
     for (int i = 0; i < nu; ++i) {
       for (int j = 0; j < nu; ++j) {
@@ -1473,8 +1523,7 @@ int aslr_cpu_quasi_static(const aslr_problem_desc_t *d, int mi, const double *fr
       for (int l = 0; l < nx; ++l) a += Fu[l * nu + i] * (xnext[l] - x[l]);
       rhs[i] = -a;
     }
-    if (chol(nu, A)) { free(rec); return -1; }
-    chol_solve(nu, A, rhs);
+    { double g[NU]; memcpy(g, rhs, sizeof(double) * nu); pinv_normal_solve(nu, nx, A, g, rhs); }
     double nrm = 0.0;
     for (int i = 0; i < nu; ++i) { u[i] += rhs[i]; nrm += rhs[i] * rhs[i]; }
     if (sqrt(nrm) <= tol) break;

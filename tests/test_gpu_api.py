@@ -222,6 +222,29 @@ def test_c5_shard_properties_and_batch_size_independence(oracle):
     assert np.abs(U[:, :2].cpu().numpy() - ref["us"]).max() < 1e-6 * scale
 
 
+def test_quasi_static_with_a_rank_deficient_fu(oracle):
+    """VSA at q_l = q_m: the stiffness columns of Fu vanish; Crocoddyl's quasiStatic takes the SVD pseudo-inverse
+    (minimum-norm update).  GPU against the oracle, the oracle against numpy's pinv."""
+    sc = scenarios.two_dof_vsa_boxddp(B=1, T=4)
+    problem = crocoddyl.ShootingProblem(sc["x0"][0], sc["running"], sc["terminal"])
+    q = np.array([0.3, -0.2])
+    x = np.concatenate([q, q, [0.1, -0.05], [0.4, 0.2]])     # q_l = q_m, moving motors
+    us = problem.quasiStatic([x] * problem.T)
+    u_ref, it = oracle.quasi_static(problem.lowered, 0, x)
+    assert it >= 0
+    np.testing.assert_allclose(us[0], u_ref, rtol=1e-8, atol=1e-9)
+    uu = np.zeros(4)
+    for _ in range(100):
+        k = oracle.knot(problem.lowered, 0, x, uu)
+        assert np.linalg.matrix_rank(k["Fu"]) < 4
+        du = -np.linalg.pinv(k["Fu"]).dot(k["xnext"] - x)
+        uu = uu + du
+        if np.linalg.norm(du) <= 1e-9:
+            break
+    assert np.abs(uu).max() > 1e-7                     # a non-trivial update (motor inertia 1e-3: micro-newton-metres)
+    np.testing.assert_allclose(u_ref, uu, rtol=1e-8, atol=1e-9)
+
+
 def test_solver_value_function_getters():
     """solver.Vx / solver.Vxx: terminal values are the terminal cost's Lx / Lxx (+ x_reg on the
     diagonal), Vxx is symmetric, and asking for them leaves the gains alone."""
