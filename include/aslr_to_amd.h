@@ -285,8 +285,9 @@ int aslr_dam_eval(aslr_problem_t *p, int32_t model_index, int32_t n, const doubl
 /* ShootingProblem.quasiStatic(xs) (examples/two_dof_sea.py:78): for every running node, the control that
  * holds XS[t] still under the node's model, by Crocoddyl's base-class Gauss-Newton
  * (u = 0; u -= pinv(Fu) (xnext - x), at most `maxiter` times, until |du| <= tol; Crocoddyl uses 100, 1e-9).
- * Reads XS; writes US.  `iters_dev` (optional DEVICE pointer, [T][B] int32) receives the iterations used,
- * -1 where Fu is rank deficient (that node's US entry is left untouched). */
+ * pinv is the thresholded pseudo-inverse (singular directions of Fu, e.g. the VSA stiffness columns at q_l = q_m,
+ * get no update).  Reads XS; writes US.  `iters_dev` (optional DEVICE pointer, [T][B] int32) receives the
+ * iterations used. */
 int aslr_quasi_static(aslr_problem_t *p, int32_t maxiter, double tol, int32_t *iters_dev, void *stream);
 
 /* last HIP error string of this thread (static storage) */
