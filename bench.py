@@ -78,7 +78,15 @@ def cpu_baseline(sc_fn, nthreads):
     r = pyoracle.solve(low, sp, nthreads=nthreads)
     dt = time.perf_counter() - t0
     iters = int(r["traj_i"][_abi.TI_ITER].sum())
+    # mode (i) of SURVEY.md 8(d): one thread, the reference's forced nthreads = 1 (first 8 trajectories)
+    sc1 = sc_fn(B=8, T=T, seed=0)
+    low1 = scenarios.lower(sc1)
+    t0 = time.perf_counter()
+    r1 = pyoracle.solve(low1, scenarios.solver_params(sc1), nthreads=1)
+    dt1 = time.perf_counter() - t0
+    single = int(r1["traj_i"][_abi.TI_ITER].sum()) * T / dt1
     return {"value": iters * T / dt, "unit": "knot-steps/s", "cores": nthreads, "kind": "port",
+            "single_thread_value": single,
             "sample": "first %d trajectories of the seed-0 batch, full BoxDDP solves (th_stop 1e-7, maxiter 400), "
                       "%d DDP iterations in %.2f s, OpenMP over trajectories" % (nsample, iters, dt),
             "single_thread_note": "the reference forces nthreads = 1 (examples/double_pendulum.py:54)"}
