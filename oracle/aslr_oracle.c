@@ -51,12 +51,6 @@ static void mat3_mul(const double *A, const double *B, double *C) {
     for (int j = 0; j < 3; ++j) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
   memcpy(C, t, sizeof t);
 }
-static void mat3T_mul(const double *A, const double *B, double *C) { /* A^T B */
-  double t[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) t[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
-  memcpy(C, t, sizeof t);
-}
 /* rotation by angle q about unit axis (Rodrigues; JointModelRevoluteUnaligned) */
 static void axis_angle(const double *ax, double q, double *R) {
   double s = sin(q), c = cos(q), v = 1.0 - c;
