@@ -160,6 +160,10 @@ struct BwdCfg {
                        sEnd = sVx + NX;
   static constexpr int LDS_TEAM = (sEnd + 1) / 2 * 2;
   static constexpr int NPRE = (REC / 2 + TEAM - 1) / TEAM; // double2 prefetch registers per lane
+  // the Fu products (Fu^T P, (Fu^T P) Fx, (Fu^T P) Fu) need all nu rows of a column: with HS lanes per column each
+  // lane takes NU / HS of them (when that divides) instead of every lane computing all of them
+  static constexpr bool SPLITU = HS > 1 && NU % HS == 0;
+  static constexpr int NUH = SPLITU ? NU / HS : NU;
 };
 
 // BOX: SolverBoxDDP gains may be needed (solver is BoxDDP); GAPS: infeasible candidates may be present
@@ -217,7 +221,10 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
   const unsigned long long team_mask = (TEAM == 64 ? ~0ull : ((1ull << TEAM) - 1ull)) << (team * TEAM);
 
   // one-hot selectors of this lane's diagonal / control row (FMA instead of compare + select in the loop)
-  double oh_row[RPL], oh_u[NU];
+  constexpr int NUH = C::NUH;
+  const int c0 = C::SPLITU ? h * NUH : 0; // first of this lane's control rows in the Fu products
+  double oh_row[RPL], oh_u[NU], oh_u0[NUH];
+  ASLR_UNROLL for (int c = 0; c < NUH; ++c) oh_u0[c] = (c0 + c == j) ? 1.0 : 0.0;
   ASLR_UNROLL for (int i = 0; i < RPL; ++i) oh_row[i] = (r0 + i == jj) ? 1.0 : 0.0;
   ASLR_UNROLL for (int c = 0; c < NU; ++c) oh_u[c] = (c == j) ? 1.0 : 0.0;
 
@@ -299,15 +306,15 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       double Fxcol[NX], Fucol[NX];
       ASLR_UNROLL for (int l = 0; l < NX; ++l) { Fxcol[l] = rec[C::oFx + l * NX + jj]; Fucol[l] = rec[C::oFu + l * NU + ju]; }
       {
-        double Arow[RPL], Bc[NU];
+        double Arow[RPL], Bc[NUH];
         ASLR_UNROLL for (int i = 0; i < RPL; ++i) Arow[i] = 0.0;
-        ASLR_UNROLL for (int c = 0; c < NU; ++c) Bc[c] = 0.0;
+        ASLR_UNROLL for (int c = 0; c < NUH; ++c) Bc[c] = 0.0;
         ASLR_UNROLL for (int l = 0; l < NX; ++l) {
           ASLR_UNROLL for (int i = 0; i < RPL; ++i) Arow[i] += rec[C::oFx + l * NX + row(i)] * Pcol[l];
-          ASLR_UNROLL for (int c = 0; c < NU; ++c) Bc[c] += rec[C::oFu + l * NU + c] * Pcol[l];
+          ASLR_UNROLL for (int c = 0; c < NUH; ++c) Bc[c] += rec[C::oFu + l * NU + c0 + c] * Pcol[l];
         }
         ASLR_UNROLL for (int i = 0; i < RPL; ++i) if (row_ok(i)) AT[jj * NX + r0 + i] = Arow[i];
-        ASLR_UNROLL for (int c = 0; c < NU; ++c) BT[jj * NU + c] = Bc[c];
+        ASLR_UNROLL for (int c = 0; c < NUH; ++c) BT[jj * NU + c0 + c] = Bc[c];
       }
       double Qx, Qu_own;
       {
@@ -320,29 +327,27 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       // ---- step 2: Qxx (my rows), Qux (column jj), Quu (column jj < NU) ----
       double Qxx[RPL], Qux[NU];
       {
-        double acc[RPL], accu[NU], accq[NU];
+        double acc[RPL], accu[NUH], accq[NUH];
         ASLR_UNROLL for (int i = 0; i < RPL; ++i) acc[i] = 0.0;
-        ASLR_UNROLL for (int c = 0; c < NU; ++c) { accu[c] = 0.0; accq[c] = 0.0; }
+        ASLR_UNROLL for (int c = 0; c < NUH; ++c) { accu[c] = 0.0; accq[c] = 0.0; }
         ASLR_UNROLL for (int l = 0; l < NX; ++l) {
           ASLR_UNROLL for (int i = 0; i < RPL; ++i) acc[i] += AT[l * NX + row(i)] * Fxcol[l];
-          ASLR_UNROLL for (int c = 0; c < NU; ++c) {
-            const double bt = BT[l * NU + c];
+          ASLR_UNROLL for (int c = 0; c < NUH; ++c) {
+            const double bt = BT[l * NU + c0 + c];
             accu[c] += bt * Fxcol[l];
             accq[c] += bt * Fucol[l];
           }
         }
         ASLR_UNROLL for (int i = 0; i < RPL; ++i) Qxx[i] = rec[C::oLxx + row(i) * NX + jj] + acc[i];
-        ASLR_UNROLL for (int c = 0; c < NU; ++c) {
-          Qux[c] = rec[C::oLxu + jj * NU + c] + accu[c];
-          QuxL[c * NX + jj] = Qux[c];
-        }
+        ASLR_UNROLL for (int c = 0; c < NUH; ++c) QuxL[(c0 + c) * NX + jj] = rec[C::oLxu + jj * NU + c0 + c] + accu[c];
         if (j < NU) {
-          ASLR_UNROLL for (int c = 0; c < NU; ++c)
-            QuuL[c * NU + j] = rec[C::oLuu + c * NU + j] + accq[c] + oh_u[c] * xr;
+          ASLR_UNROLL for (int c = 0; c < NUH; ++c)
+            QuuL[(c0 + c) * NU + j] = rec[C::oLuu + (c0 + c) * NU + j] + accq[c] + oh_u0[c] * xr;
           QuL[j] = Qu_own;
         }
       }
       wave_sync();
+      ASLR_UNROLL for (int c = 0; c < NU; ++c) Qux[c] = QuxL[c * NX + jj];
       // ---- step 3: gains (redundant per lane) ----
       double Quu[NU][NU], qu[NU], kv[NU], Kc[NU];
       ASLR_UNROLL for (int c = 0; c < NU; ++c) {
