@@ -121,8 +121,9 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
     // chunks of structural zeros (all of Lxu, most of Lxx / Luu for the larger chain) were written once, by the
     // zero fill of DERIV at problem creation
     if constexpr (rec_chunk_is_zero<NJ, NU, c, kChunk>()) return;
-    // chunks that depend on the model only (cost-weight diagonals of Lxx / Luu) are written by the first full sweep
-    if constexpr (rec_chunk_is_model_only<NJ, NU, c, kChunk>()) {
+    // chunks that depend on the model only (cost-weight diagonals of Lxx / Luu; all of Fu for SEA) are written by the
+    // first full sweep
+    if constexpr (rec_chunk_is_model_only<NJ, NU, c, kChunk, DAM == ASLR_DAM_SEA>()) {
       if (mode & kModeSkipConst) return;
     }
     if (compute) {

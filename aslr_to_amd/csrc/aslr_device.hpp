@@ -1255,21 +1255,23 @@ constexpr bool rec_elem_is_zero() {
 // model-only test of record element E: structural zero, or a diagonal entry of Lxx outside the nj x nj block /
 // of Luu, which is a sum of cost weights (state and control regularisers) and does not depend on the knot -- PROVIDED
 // the cost stack has no cost with a state-dependent diagonal Hessian (CostModelDoublePendulum; the host checks)
-template <int NJ, int NU, int E>
+// (SEA: Fu = dt [dt a_u; a_u] with a_u = [0; B^-1 S] -- free_fwddyn_asr.py:86-88 -- has no state in it either)
+template <int NJ, int NU, int E, bool SEA = false>
 constexpr bool rec_elem_is_model_only() {
   using L = RecLayout<NJ, NU>;
   constexpr int NX = L::NX;
   if (rec_elem_is_zero<NJ, NU, E>()) return true;
+  if (SEA && E >= L::oFu && E < L::oLxx) return true;
   if (E >= L::oLxx && E < L::oLxu) {
     constexpr int e = E - L::oLxx, r = e / NX, cc = e % NX;
     return r == cc && r >= NJ;
   }
   return E >= L::oLuu && E < L::oLx;
 }
-template <int NJ, int NU, int C, int CHUNK, int I = 0>
+template <int NJ, int NU, int C, int CHUNK, bool SEA = false, int I = 0>
 constexpr bool rec_chunk_is_model_only() {
   if constexpr (I == CHUNK) return true;
-  else return rec_elem_is_model_only<NJ, NU, C * CHUNK + I>() && rec_chunk_is_model_only<NJ, NU, C, CHUNK, I + 1>();
+  else return rec_elem_is_model_only<NJ, NU, C * CHUNK + I, SEA>() && rec_chunk_is_model_only<NJ, NU, C, CHUNK, SEA, I + 1>();
 }
 template <int NJ, int NU, int C, int CHUNK, int I = 0>
 constexpr bool rec_chunk_is_zero() {
