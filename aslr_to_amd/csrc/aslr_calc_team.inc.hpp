@@ -125,9 +125,9 @@ struct CalcTeam {
 };
 
 // mode: calc_kernel's (kModeCommit: read the accepted candidate; kModeSolver: honour RECALC / DONE).
-// PHASE 0: M, nonlinear effects, M^-1, accelerations; PHASE 1: dtau/dq; PHASE 2: dtau/dv.  Three launches of
-// the same body: each phase gets its own register allocation (together they need > 512 VGPRs and spill), the
-// kept sweep (1 of the 24) is simply recomputed by phases 1 and 2.
+// PHASE 0: M, nonlinear effects, M^-1, accelerations; PHASE 1: the kept sweep, dtau/dq and dtau/dv.  Two launches of
+// the same body: each phase gets its own register allocation (262 and 436 VGPRs, no scratch; in one kernel the first
+// part would run at the occupancy of the second: measured 706 vs 684 us for the whole calcDiff).
 template <int NJ, int PHASE>
 __global__ void __launch_bounds__(64) dyn_team_kernel(KArgs a, int mode) {
   using C = CalcTeam<NJ>;
@@ -219,14 +219,16 @@ __global__ void __launch_bounds__(64) dyn_team_kernel(KArgs a, int mode) {
       if (jl && compute) { out[c] = al; out[NJ + c] = am; }
     }
   } else {
-    // ---- RNEA(q, v, a_link) keeping its intermediates, then one tangent sweep per lane ----
+    // ---- RNEA(q, v, a_link) keeping its intermediates, then the two tangent sweeps of this lane ----
     if (jl) xoL[c] = out[c]; // link accelerations of phase 0
     wave_sync();
     rnea_keep_lds<NJ>(chc, RL, xT + 2 * NJ, xoL, WS, c == 0);
     wave_sync();
     double *colL = ML + 8 * c;
-    rnea_tangent_lds<NJ, PHASE - 1>(chc, RL, WS, xT + 2 * NJ, cj, colL);
-    if (jl && compute) { ASLR_UNROLL for (int i = 0; i < NJ; ++i) out[2 * NJ + PHASE * NJ * NJ + i * NJ + c] = colL[i]; }
+    rnea_tangent_lds<NJ, 0>(chc, RL, WS, xT + 2 * NJ, cj, colL);
+    if (jl && compute) { ASLR_UNROLL for (int i = 0; i < NJ; ++i) out[2 * NJ + NJ * NJ + i * NJ + c] = colL[i]; }
+    rnea_tangent_lds<NJ, 1>(chc, RL, WS, xT + 2 * NJ, cj, colL);
+    if (jl && compute) { ASLR_UNROLL for (int i = 0; i < NJ; ++i) out[2 * NJ + 2 * NJ * NJ + i * NJ + c] = colL[i]; }
   }
 }
 
