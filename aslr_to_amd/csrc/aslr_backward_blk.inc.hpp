@@ -132,7 +132,8 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
       __syncthreads();
       if (gaps_on && tid < NX) {
         double vf = 0.0;
-        for (int q = 0; q < NX; ++q) vf += PT[tid * NX + q] * FL[q];
+        { const double2 *pr = reinterpret_cast<const double2 *>(PT + tid * NX), *fr = reinterpret_cast<const double2 *>(FL);
+          ASLR_UNROLL for (int q = 0; q < NX / 2; ++q) { const double2 pv = pr[q], fv = fr[q]; vf += pv.x * fv.x; vf += pv.y * fv.y; } }
         Vx_own += vf;
         if (fddp) {
           dgf -= Vx_own * FL[tid];
@@ -403,7 +404,8 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
         __syncthreads();
         if (tid < NX) {
           double vf = 0.0;
-          for (int q = 0; q < NX; ++q) vf += PT[tid * NX + q] * FL[q];
+          const double2 *pr = reinterpret_cast<const double2 *>(PT + tid * NX), *fr = reinterpret_cast<const double2 *>(FL);
+          ASLR_UNROLL for (int q = 0; q < NX / 2; ++q) { const double2 pv = pr[q], fv = fr[q]; vf += pv.x * fv.x; vf += pv.y * fv.y; }
           Vx_own += vf;
           if (fddp) {
             dgf -= Vx_own * FL[tid];

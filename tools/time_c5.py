@@ -12,7 +12,7 @@ def timeit(fn, n=5):
     fn(); torch.cuda.synchronize(); a, b = ev(), ev(); a.record()
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / n * 1e3
-sp = scenarios.solver_params(sc, solver="SolverDDP", fixed_iterations=1)
+sp = scenarios.solver_params(sc, solver=(sys.argv[2] if len(sys.argv) > 2 else "SolverDDP"), fixed_iterations=1)
 for i in range(5): e.iterate(sp, i == 0)
 torch.cuda.synchronize()
 print("B=%d 7-DoF SEA DDP T=150: iterate %.1f us, backward %.1f us, forward %.1f us, calc_diff %.1f us, calc %.1f us" % (
