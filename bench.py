@@ -146,6 +146,17 @@ def main():
     torch.cuda.synchronize(dev)
     stats = dist.all_reduce_stats(dist.local_stats(e))  # the ONE collective of a solve (RCCL over xGMI)
 
+    # converge mode: the example's own solve -- th_stop 1e-7, maxiter 400, exit when every
+    # trajectory of the shard has stopped -- timed once, outside the figure of merit above
+    spc = scenarios.solver_params(sc)
+    e.set_candidate(None, None)
+    torch.cuda.synchronize(dev)
+    tc0 = time.perf_counter()
+    batch_iters = e.solve(spc, poll_every=4)
+    torch.cuda.synchronize(dev)
+    conv_wall = dist.max_over_ranks(time.perf_counter() - tc0, dev)
+    cstats = dist.all_reduce_stats(dist.local_stats(e))
+
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -175,6 +186,12 @@ def main():
         "ddp_iterations_per_s": args.steps / elapsed,
         "trajectory_iterations_per_s": Bg * world * args.steps / elapsed,
         "line_search_trials_per_iteration": trials,
+        "line_search_rollouts_per_s": 10 * Bg * world * args.steps / elapsed,   # every step length is rolled out
+        "converge_mode": {"wall_s": conv_wall, "lock_step_iterations": int(batch_iters), "converged": cstats["converged"],
+                          "trajectory_iterations": cstats["iters_sum"],
+                          "useful_knot_steps_per_s": cstats["iters_sum"] * T / conv_wall,
+                          "note": "th_stop 1e-7, maxiter 400, all trajectories iterate in lock-step until the last "
+                                  "one stops; useful = iterations each trajectory needed"},
         "kernel_ms": dict(zip(names, k_ms)),
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc_names[dom]),
