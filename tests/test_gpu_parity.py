@@ -255,6 +255,30 @@ def test_three_action_models_along_the_horizon_match_oracle(oracle):
     assert (U[:15, :, 2:] >= 0.0).all()          # the first model's stiffness bound holds on its knots
 
 
+def test_solve_matches_oracle_on_a_larger_batch(oracle):
+    """128 BoxDDP trajectories of another seed, full solves (the oracle runs them on the host cores): every
+    trajectory must take the same number of iterations and end with the same status word; the converged ones agree
+    within north_star's tolerances."""
+    import os
+    sc = scenarios.two_dof_vsa_boxddp(B=128, T=100, seed=11)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc)
+    ref = oracle.solve(low, sp, nthreads=min(16, len(os.sched_getaffinity(0))))
+    e = _engine(low)
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=4)
+    _sync()
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER])
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)), ref["traj_i"][_abi.TI_STATUS])
+    conv = (ref["traj_i"][_abi.TI_STATUS] & _abi.ST_CONVERGED) != 0
+    assert conv.sum() > 100
+    dx = np.abs(_np(e.region(_abi.R_XS)) - ref["xs"])[:, conv].max()
+    du = np.abs(_np(e.region(_abi.R_US)) - ref["us"])[:, conv].max()
+    dc = np.abs(_np(e.traj_f(_abi.TF_COST)) - ref["traj_f"][_abi.TF_COST])[conv].max()
+    print("128 trajectories: converged %d, dx %.2e du %.2e dcost %.2e" % (conv.sum(), dx, du, dc))
+    assert dx < 1e-6 and du < 1e-6 and dc < 1e-4
+
+
 def _indefinite_sea(B, T, cost_name, weight):
     """SEA problem with one NEGATIVE cost weight: Quu / Vxx turn indefinite, so backward passes fail
     (Cholesky "backward_error" -> increaseRegularization -> retry without recalc) and the
