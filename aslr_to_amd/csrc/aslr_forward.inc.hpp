@@ -130,11 +130,11 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
 
 // cost of every stored candidate knot: COST_TRY[a][t][b]
 template <int NJ, int DAM, bool PLANAR>
-__global__ void __launch_bounds__(256) trial_cost_kernel(KArgs a, SolverDev sp) {
+__global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
   using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
   const int B = a.B, T = a.T, t = blockIdx.y, ai = blockIdx.z;
-  const int bq = blockIdx.x * 256 + threadIdx.x;
+  const int bq = blockIdx.x * 64 + threadIdx.x;
   const bool valid = bq < B;
   const int b = valid ? bq : B - 1;
   const int done = sp.standalone ? 0 : a.traj_i[ASLR_TI_DONE * B + b];

@@ -4,8 +4,8 @@
 
 namespace aslr {
 int launch_forward_nj7(const KArgs &k, int dam, const SolverDev &sd, const ModelLimits &lim, hipStream_t st) {
-  dim3 block(64), cgrid((k.B + 255) / 256, k.T + 1, ASLR_NALPHA), sgrid((k.B + 63) / 64),
-      cblock(256), ugrid((k.B + 63) / 64, ASLR_NALPHA);
+  dim3 block(64), cgrid((k.B + 63) / 64, k.T + 1, ASLR_NALPHA), sgrid((k.B + 63) / 64),
+      cblock(64), ugrid((k.B + 63) / 64, ASLR_NALPHA);
   if (dam == ASLR_DAM_SEA) {
     {
       // one block of 16 eight-lane teams per trajectory (aslr_forward_team.inc.hpp)
