@@ -279,6 +279,39 @@ def test_solve_matches_oracle_on_a_larger_batch(oracle):
     assert dx < 1e-6 and du < 1e-6 and dc < 1e-4
 
 
+@pytest.mark.parametrize("name,kw,solver,maxiter", [
+    ("double_pendulum", dict(T=100), "SolverDDP", 15),        # C1 as BASELINE.json states it (T = 100, SolverDDP)
+    ("double_pendulum", dict(T=100), "SolverFDDP", 15),
+    ("two_dof_vsa_boxddp", dict(B=8, T=100), "SolverDDP", 15),   # the VSA models under the unconstrained solvers
+    ("two_dof_vsa_boxddp", dict(B=8, T=100), "SolverFDDP", 15),
+    # cold-started plain DDP on the 7-DoF arm: its first full step throws the iterates to ~6e3 and one of the four
+    # trajectories then creeps back with step lengths of 1/16: rounding differences (3e-10 relative after the
+    # first iteration) grow ~2x per iteration on it (tools/diverge.py); 6 iterations are compared
+    ("talos_arm_sea", dict(B=4, T=60), "SolverDDP", 6),
+])
+def test_first_iterations_match_oracle(oracle, name, kw, solver, maxiter):
+    """The first iterations from the cold start (these runs do not all converge within their cap): solver state
+    exactly, iterates relative to their size."""
+    sc = scenarios.SCENARIOS[name](**kw)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc, solver=solver, maxiter=maxiter)
+    ref = oracle.solve(low, sp)
+    e = _engine(low)
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=4)
+    _sync()
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER])
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)), ref["traj_i"][_abi.TI_STATUS])
+    np.testing.assert_allclose(_np(e.traj_f(_abi.TF_XREG)), ref["traj_f"][_abi.TF_XREG], rtol=0)
+    np.testing.assert_allclose(_np(e.traj_f(_abi.TF_STEP)), ref["traj_f"][_abi.TF_STEP], rtol=0)
+    scale = max(1.0, np.abs(ref["xs"]).max(), np.abs(ref["us"]).max())
+    dx = np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max()
+    du = np.abs(_np(e.region(_abi.R_US)) - ref["us"]).max()
+    dc = np.abs(_np(e.traj_f(_abi.TF_COST)) - ref["traj_f"][_abi.TF_COST]).max()
+    print(name, solver, "dx %.2e du %.2e dcost %.2e scale %.2e" % (dx, du, dc, scale))
+    assert dx < 1e-6 * scale and du < 1e-6 * scale
+
+
 def _indefinite_sea(B, T, cost_name, weight):
     """SEA problem with one NEGATIVE cost weight: Quu / Vxx turn indefinite, so backward passes fail
     (Cholesky "backward_error" -> increaseRegularization -> retry without recalc) and the

@@ -15,7 +15,7 @@ low = scenarios.lower(sc)
 e = Engine(low)
 np.set_printoptions(linewidth=200, precision=3)
 for k in range(1, KMAX + 1):
-    sp = scenarios.solver_params(sc, maxiter=k)
+    sp = scenarios.solver_params(sc, maxiter=k, **({"solver": sys.argv[5]} if len(sys.argv) > 5 else {}))
     r = po.solve(low, sp)
     e.set_candidate(None, None)
     e.solve(sp, poll_every=0)
