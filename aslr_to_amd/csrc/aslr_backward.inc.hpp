@@ -11,6 +11,7 @@
 // 4 teams), so the code avoids selects / clamps / divisions in the loop: rows divide evenly for
 // nx = 8, pivots use rsqrt, the NaN test is one sum per lane.
 #pragma once
+#include <utility>
 #include "aslr_common.hpp"
 
 namespace aslr {
@@ -45,18 +46,20 @@ ASLR_DEV bool chol_rs(double (&A)[N][N], double (&rinv)[N]) {
 // a wave step together (wave-uniform loop control by ballot); a team that has converged keeps its
 // state through selects and its factor is simply rebuilt from its (final) mask.
 // A team whose line search rejects all step lengths stops at once (its state can no longer change).
+// In: x = the warm start already clamped to the box, g = q + H x there (the caller has both from its replay of
+// the first active-set test).  The objective value travels with x: the accepted trial's f is the next
+// iteration's f(x), so H x is formed once per call.
 // On exit: x, the clamped flags of the final active set, and kcol <- Quu_inv kcol where Quu_inv is
 // Hff^-1 on the free block and zero elsewhere (Crocoddyl forms Hff^-1 explicitly and multiplies; solving
 // with the same factor differs by rounding only).
 template <int NU>
 ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const double (&lb)[NU],
-                    const double (&ub)[NU], double (&x)[NU], bool (&cm)[NU], double (&kcol)[NU],
+                    const double (&ub)[NU], double (&x)[NU], double (&g)[NU], bool (&cm)[NU], double (&kcol)[NU],
                     int boxqp_maxiter, double th_acceptstep, double th_grad, double reg) {
   bool bad = false, finished = false;
   double mk[NU], mkL[NU], L[NU][NU], rinv[NU];
   ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-    x[i] = fmax(fmin(x[i], ub[i]), lb[i]);
-    mk[i] = 1.0; mkL[i] = -1.0; cm[i] = false; rinv[i] = 1.0;
+    mk[i] = 1.0; mkL[i] = -1.0; rinv[i] = 1.0;
     ASLR_UNROLL for (int j = 0; j < NU; ++j) L[i][j] = 0.0;
   }
   auto factor = [&]() {
@@ -67,28 +70,22 @@ ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const doub
     }
     return chol_rs<NU>(L, rinv);
   };
+  // f(x) = 1/2 x^T H x + q^T x
+  double fold = 0.0;
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+    double s = 0.0;
+    ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
+    fold += 0.5 * x[i] * s + q[i] * x[i];
+  }
   for (int it = 0; it < boxqp_maxiter; ++it) {
-    double g[NU], Hx[NU];
-    ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-      double s = 0.0;
-      ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
-      Hx[i] = s;
-      g[i] = q[i];
-    }
-    // g = q + H x accumulated in the oracle's order (q first)
-    ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-      double s = q[i];
-      ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
-      g[i] = s;
-    }
     double gnorm = 0.0, nfree = 0.0;
-    bool cmn[NU];
     ASLR_UNROLL for (int j = 0; j < NU; ++j) {
-      cmn[j] = (x[j] == lb[j] && g[j] > 0.0) || (x[j] == ub[j] && g[j] < 0.0);
-      const double mj = cmn[j] ? 0.0 : 1.0;
+      // (plain & / |: four compares and three mask operations, no short-circuit branches)
+      const bool at_lb = (x[j] == lb[j]) & (g[j] > 0.0), at_ub = (x[j] == ub[j]) & (g[j] < 0.0);
+      const double mj = (at_lb | at_ub) ? 0.0 : 1.0;
       gnorm = fmax(gnorm, mj * fabs(g[j]));
       nfree += mj;
-      if (!finished) { cm[j] = cmn[j]; mk[j] = mj; }
+      mk[j] = finished ? mk[j] : mj;
     }
     const bool fin_now = finished || (gnorm <= th_grad) || (nfree == 0.0);
     if (__ballot(!fin_now) == 0ull) { finished = true; break; }
@@ -103,12 +100,8 @@ ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const doub
       rhs[i] = mk[i] * s;
     }
     chol_solve_r<NU>(L, rinv, rhs);
-    double fold = 0.0;
-    ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-      dx[i] = mk[i] * (rhs[i] - x[i]);
-      fold += 0.5 * x[i] * Hx[i] + q[i] * x[i];
-    }
-    double alpha = 1.0;
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) dx[i] = mk[i] * (rhs[i] - x[i]);
+    double alpha = 1.0, fnext = fold;
     bool found = !stepping;
     for (int al = 0; al < ASLR_NALPHA; ++al, alpha *= 0.5) {
       double xn[NU], fnew = 0.0, gd = 0.0;
@@ -121,12 +114,20 @@ ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const doub
       }
       const bool take = !found && (fold - fnew > th_acceptstep * gd);
       ASLR_UNROLL for (int i = 0; i < NU; ++i) x[i] = take ? xn[i] : x[i];
+      fnext = take ? fnew : fnext;
       found = found || take;
       if (__ballot(!found) == 0ull) break;
     }
+    fold = fnext;
     // No step length accepted: x is unchanged, so every remaining iteration would recompute the same
     // gradient, active set and rejected steps and return this x.  Stop here with that result.
     finished = fin_now || cbad || !found;
+    // gradient at the new point, accumulated in the oracle's order (q first)
+    ASLR_UNROLL for (int i = 0; i < NU; ++i) {
+      double s = q[i];
+      ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
+      g[i] = s;
+    }
   }
   // factor of the final free block: the one at hand unless the active set changed in the last step
   bool stale = false;
@@ -136,7 +137,7 @@ ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const doub
     ASLR_UNROLL for (int i = 0; i < NU; ++i) nfree += mk[i];
     if (factor() && nfree > 0.0) bad = true;
   }
-  ASLR_UNROLL for (int i = 0; i < NU; ++i) kcol[i] *= mk[i];
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) { cm[i] = (mk[i] == 0.0); kcol[i] *= mk[i]; }
   chol_solve_r<NU>(L, rinv, kcol);
   ASLR_UNROLL for (int i = 0; i < NU; ++i) kcol[i] *= mk[i];
   return bad;
@@ -164,7 +165,47 @@ struct BwdCfg {
   // lane takes NU / HS of them (when that divides) instead of every lane computing all of them
   static constexpr bool SPLITU = HS > 1 && NU % HS == 0;
   static constexpr int NUH = SPLITU ? NU / HS : NU;
+  // DMA: the record of the next knot (and its [us | k | gap] inputs) goes from HBM straight into LDS
+  // (global_load_lds_dwordx4: every lane fetches 16 bytes, the wave's 64 pieces land contiguously), issued once
+  // this knot's record has been consumed, so no prefetch registers stay live across the gains / box-QP phase.
+  // One instruction covers a block of BS doubles of each team's record: element e of team tm sits at
+  // (e / BS) * DMAW + tm * BS + e % BS.
+  static constexpr bool DMA = (NX == 8 && HS == 2 && TPW == 4 && NU % 2 == 0);
+  static constexpr int BS = 2 * TEAM, DMAW = 128;
+  static constexpr int AUXL = NU + NX / 2; // lanes of a team that fetch the small inputs
+  static constexpr int ridx(int e) { return (e / BS) * DMAW + e % BS; }
+  // every (constant + per-lane offset) access of the kernel must stay inside one block
+  static constexpr bool in_block(int cst, int rtmax) { return cst % BS + rtmax < BS; }
+  static constexpr bool dma_layout_ok() {
+    bool ok = (RPL * NX == BS) && (REC % 2 == 0) && (AUXL <= TEAM);
+    for (int l = 0; l < NX; ++l) {
+      for (int i = 0; i < RPL; ++i) ok = ok && in_block(oFx + l * NX + i, (HS - 1) * RPL);
+      for (int c = 0; c < NUH; ++c) ok = ok && in_block(oFu + l * NU + c, (HS - 1) * NUH);
+      ok = ok && in_block(oFx + l * NX, NX - 1) && in_block(oFu + l * NU, NU - 1);
+    }
+    ok = ok && in_block(oLx, NX - 1) && in_block(oLu, NU - 1);
+    for (int i = 0; i < RPL; ++i) ok = ok && in_block(oLxx + i * NX, NX - 1);
+    for (int c = 0; c < NUH; ++c)
+      ok = ok && in_block(oLxu + c, (NX - 1) * NU + (HS - 1) * NUH) && in_block(oLuu + c * NU, (HS - 1) * NUH * NU + NU - 1);
+    return ok;
+  }
+  static_assert(!DMA || dma_layout_ok(), "record layout does not fit the LDS-DMA blocks");
 };
+
+typedef __attribute__((address_space(3))) void *lds_void_p;
+typedef __attribute__((address_space(3))) char *lds_char_p;
+typedef __attribute__((address_space(1))) const void *glb_void_p;
+
+// One record through LDS-DMA: piece I of every team with instruction offset I * BS * 8, which moves the global
+// address by I blocks and the LDS address by the same number of bytes (hence the DMAW - BS stride of the bases).
+template <int OFF>
+ASLR_DEV void dma16(const char *g, lds_char_p l) {
+  __builtin_amdgcn_global_load_lds((glb_void_p)g, (lds_void_p)l, 16, OFF, 0);
+}
+template <class C, int... I>
+ASLR_DEV void dma_record(const char *g, lds_char_p recD, int lt, std::integer_sequence<int, I...>) {
+  ((C::NPRE * C::TEAM == C::REC / 2 || lt + C::TEAM * I < C::REC / 2 ? dma16<I * C::BS * 8>(g, recD + I * (C::DMAW - C::BS) * 8) : (void)0), ...);
+}
 
 // BOX: SolverBoxDDP gains may be needed (solver is BoxDDP); GAPS: infeasible candidates may be present
 // (gap terms, FDDP expected-improvement terms).  A wave whose trajectories need neither runs the lean variant.
@@ -172,7 +213,7 @@ template <int NX, int NU, int HS, int TPWA, bool BOX, bool GAPS>
 __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
   using C = BwdCfg<NX, NU, HS, TPWA>;
   constexpr int NXP = C::NXP, TEAM = C::TEAM, TPW = C::TPW, RPL = C::RPL, REC = C::REC;
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
 
   const int lane = threadIdx.x, team = lane / TEAM, lt = lane % TEAM, j = lt % NXP, h = lt / NXP;
   const int B = a.B, T = a.T;
@@ -187,6 +228,11 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
   double *sm = smem + (team < TPW ? team : 0) * C::LDS_TEAM;
   double *rec = sm + C::sRec, *AT = sm + C::sAT, *BT = sm + C::sBT, *QuxL = sm + C::sQux, *VT = sm + C::sVT,
          *QuuL = sm + C::sQuu, *QuL = sm + C::sQu, *VxL = sm + C::sVx;
+  __shared__ __attribute__((aligned(16))) double recD[C::DMA ? C::NPRE * C::DMAW : 2];
+  __shared__ __attribute__((aligned(16))) double auxD[C::DMA ? 2 * C::DMAW : 2];
+  const double *recT = recD + (C::DMA ? team * C::BS : 0);
+  // record element (compile-time part cst, per-lane part rt)
+  auto R = [&](int cst, int rt) -> double { return C::DMA ? recT[C::ridx(cst) + rt] : rec[cst + rt]; };
   auto row = [&](int i) { return C::EXACT ? r0 + i : (r0 + i < NX ? r0 + i : NX - 1); };
   auto row_ok = [&](int i) { return C::EXACT ? true : (r0 + i < NX); };
 
@@ -276,7 +322,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         const int idx = lt + TEAM * i;                                                                 \
         if (C::NPRE * TEAM == REC / 2 || idx < REC / 2) { const nt_double2 v2 = __builtin_nontemporal_load(src + idx); prx[i] = v2.x; pry[i] = v2.y; } \
       }                                                                                                \
-      pre_m = a.node_model[tt];                                                                        \
+      pre_m = node_model_c[tt];                                                                        \
       if (box) {                                                                                       \
         ASLR_UNROLL for (int c = 0; c < NU; ++c) { pre_u[c] = a.us[tbp * NU + c]; pre_k[c] = a.kff[tbp * NU + c]; } \
       }                                                                                                \
@@ -284,34 +330,58 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         ASLR_UNROLL for (int r = 0; r < NX; ++r) pre_f[r] = a.gaps[tbp * NX + r];                      \
       }                                                                                                \
     } while (0)
-    ASLR_BWD_PREFETCH(T - 1);
+    // DMA variant: record pieces and the small inputs of knot tt straight into LDS (aux slot by parity of tt)
+#define ASLR_BWD_DMA(tt)                                                                               \
+    do {                                                                                               \
+      const char *kb = reinterpret_cast<const char *>(a.deriv + (size_t)(tt) * B * REC); /* uniform */ \
+      dma_record<C>(kb + rec_voff, (lds_char_p)recD, lt, std::make_integer_sequence<int, C::NPRE>());  \
+      if (aux_on) __builtin_amdgcn_global_load_lds((glb_void_p)(aux_src + (size_t)(tt) * aux_step), (lds_void_p)(auxD + ((tt) & 1) * C::DMAW), 16, 0, 0); \
+      pre_m = node_model_c[tt];                                                                        \
+    } while (0)
+    // per-lane byte offset of this lane's 16-byte piece inside a knot's slab of records (B * REC * 8 < 2^32)
+    const unsigned rec_voff = (unsigned)b * (unsigned)(REC * 8) + (unsigned)lt * 16u;
+    // which of the small inputs this lane fetches: lanes [0, nu/2) us, [nu/2, nu) k, [nu, nu + nx/2) the gap
+    const size_t aux_stride = lt < NU ? NU : NX;
+    const double *aux_src = (lt < NU / 2 ? a.us + 2 * lt : (lt < NU ? a.kff + 2 * (lt - NU / 2) : a.gaps + 2 * (lt - NU))) + (size_t)b * aux_stride;
+    const size_t aux_step = (size_t)B * aux_stride; // doubles per knot
+    const bool aux_on = lt < NU ? box : (gaps_on && lt < C::AUXL);
+    const int32_t __attribute__((address_space(4))) *node_model_c =
+        (const int32_t __attribute__((address_space(4))) *)(a.node_model); // read-only table: scalar loads
+    if (C::DMA) ASLR_BWD_DMA(T - 1); else ASLR_BWD_PREFETCH(T - 1);
     for (int t = T - 1; t >= 0; --t) {
       const size_t tb = (size_t)t * B + b;
-      // stage the record in LDS, take this knot's small inputs, start the next loads
-      {
+      const double *auxT = auxD + (C::DMA ? (t & 1) * C::DMAW + team * C::BS : 0); // [us | k | gap] of this knot
+      double ut[NU], k0[NU], fg[NX];
+      if (C::DMA) {
+        // the record of this knot (issued during the previous one) has landed
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+        wave_sync();
+      } else {
+        // stage the record in LDS, take this knot's small inputs, start the next loads
         double2 *dst = reinterpret_cast<double2 *>(rec);
         ASLR_UNROLL for (int i = 0; i < C::NPRE; ++i) {
           const int idx = lt + TEAM * i;
           if (C::NPRE * TEAM == REC / 2 || idx < REC / 2) { double2 v2; v2.x = prx[i]; v2.y = pry[i]; dst[idx] = v2; }
         }
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) { ut[c] = pre_u[c]; k0[c] = pre_k[c]; }
+        ASLR_UNROLL for (int r = 0; r < NX; ++r) fg[r] = pre_f[r];
       }
-      double ut[NU], k0[NU], fg[NX];
-      ASLR_UNROLL for (int c = 0; c < NU; ++c) { ut[c] = pre_u[c]; k0[c] = pre_k[c]; }
-      ASLR_UNROLL for (int r = 0; r < NX; ++r) fg[r] = pre_f[r];
       const int mi = pre_m;
-      wave_sync();
-      if (t > 0) ASLR_BWD_PREFETCH(t - 1);
+      if (!C::DMA) {
+        wave_sync();
+        if (t > 0) ASLR_BWD_PREFETCH(t - 1);
+      }
 
       // ---- step 1: A = Fx^T P (my rows of column jj), Bc = Fu^T P (column jj), Qx, Qu ----
       double Fxcol[NX], Fucol[NX];
-      ASLR_UNROLL for (int l = 0; l < NX; ++l) { Fxcol[l] = rec[C::oFx + l * NX + jj]; Fucol[l] = rec[C::oFu + l * NU + ju]; }
+      ASLR_UNROLL for (int l = 0; l < NX; ++l) { Fxcol[l] = R(C::oFx + l * NX, jj); Fucol[l] = R(C::oFu + l * NU, ju); }
       {
         double Arow[RPL], Bc[NUH];
         ASLR_UNROLL for (int i = 0; i < RPL; ++i) Arow[i] = 0.0;
         ASLR_UNROLL for (int c = 0; c < NUH; ++c) Bc[c] = 0.0;
         ASLR_UNROLL for (int l = 0; l < NX; ++l) {
-          ASLR_UNROLL for (int i = 0; i < RPL; ++i) Arow[i] += rec[C::oFx + l * NX + row(i)] * Pcol[l];
-          ASLR_UNROLL for (int c = 0; c < NUH; ++c) Bc[c] += rec[C::oFu + l * NU + c0 + c] * Pcol[l];
+          ASLR_UNROLL for (int i = 0; i < RPL; ++i) Arow[i] += (C::DMA ? R(C::oFx + l * NX + i, r0) : rec[C::oFx + l * NX + row(i)]) * Pcol[l];
+          ASLR_UNROLL for (int c = 0; c < NUH; ++c) Bc[c] += R(C::oFu + l * NU + c, c0) * Pcol[l];
         }
         ASLR_UNROLL for (int i = 0; i < RPL; ++i) if (row_ok(i)) AT[jj * NX + r0 + i] = Arow[i];
         ASLR_UNROLL for (int c = 0; c < NUH; ++c) BT[jj * NU + c0 + c] = Bc[c];
@@ -320,8 +390,8 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       {
         double s = 0.0, s2 = 0.0;
         ASLR_UNROLL for (int l = 0; l < NX; ++l) { s += Fxcol[l] * pvec[l]; s2 += Fucol[l] * pvec[l]; }
-        Qx = rec[C::oLx + jj] + s;
-        Qu_own = rec[C::oLu + ju] + s2;
+        Qx = R(C::oLx, jj) + s;
+        Qu_own = R(C::oLu, ju) + s2;
       }
       wave_sync();
       // ---- step 2: Qxx (my rows), Qux (column jj), Quu (column jj < NU) ----
@@ -338,16 +408,24 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
             accq[c] += bt * Fucol[l];
           }
         }
-        ASLR_UNROLL for (int i = 0; i < RPL; ++i) Qxx[i] = rec[C::oLxx + row(i) * NX + jj] + acc[i];
-        ASLR_UNROLL for (int c = 0; c < NUH; ++c) QuxL[(c0 + c) * NX + jj] = rec[C::oLxu + jj * NU + c0 + c] + accu[c];
+        ASLR_UNROLL for (int i = 0; i < RPL; ++i) Qxx[i] = (C::DMA ? recT[C::ridx(C::oLxx + i * NX) + jj + h * C::DMAW] : rec[C::oLxx + row(i) * NX + jj]) + acc[i];
+        ASLR_UNROLL for (int c = 0; c < NUH; ++c) QuxL[(c0 + c) * NX + jj] = R(C::oLxu + c, jj * NU + c0) + accu[c];
         if (j < NU) {
           ASLR_UNROLL for (int c = 0; c < NUH; ++c)
-            QuuL[(c0 + c) * NU + j] = rec[C::oLuu + (c0 + c) * NU + j] + accq[c] + oh_u0[c] * xr;
+            QuuL[(c0 + c) * NU + j] = R(C::oLuu + c * NU, c0 * NU + j) + accq[c] + oh_u0[c] * xr;
           QuL[j] = Qu_own;
         }
       }
       wave_sync();
       ASLR_UNROLL for (int c = 0; c < NU; ++c) Qux[c] = QuxL[c * NX + jj];
+      if (C::DMA) {
+        // this knot's record is consumed: take the control inputs, then let the next knot's loads fly
+        // under the gains phase
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) { ut[c] = auxT[c]; k0[c] = auxT[NU + c]; } // (used by box nodes only)
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): every LDS read of the record has returned
+        wave_sync();
+        if (t > 0) ASLR_BWD_DMA(t - 1);
+      }
       // ---- step 3: gains (redundant per lane) ----
       double Quu[NU][NU], qu[NU], kv[NU], Kc[NU];
       ASLR_UNROLL for (int c = 0; c < NU; ++c) {
@@ -359,7 +437,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       const bool boxed = box && lim.has[mi];
       double lb[NU], ub[NU], x0[NU];
       bool any_clamped = false;
-      double gnorm0 = 0.0;
+      double gnorm0 = 0.0, g0[NU];
       if (boxed) {
         ASLR_UNROLL for (int c = 0; c < NU; ++c) {
           lb[c] = lim.lb[mi][c] - ut[c];
@@ -369,7 +447,8 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         ASLR_UNROLL for (int c = 0; c < NU; ++c) {
           double sg = qu[c];
           ASLR_UNROLL for (int e = 0; e < NU; ++e) sg += Quu[c][e] * x0[e];
-          any_clamped = any_clamped || (x0[c] == lb[c] && sg > 0.0) || (x0[c] == ub[c] && sg < 0.0);
+          g0[c] = sg;
+          any_clamped = any_clamped | ((x0[c] == lb[c]) & (sg > 0.0)) | ((x0[c] == ub[c]) & (sg < 0.0));
           gnorm0 = fmax(gnorm0, fabs(sg));
         }
       }
@@ -409,13 +488,19 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         } else {
           double xq[NU];
           bool cm[NU];
-          ASLR_UNROLL for (int c = 0; c < NU; ++c) { xq[c] = k0[c]; Kc[c] = Qux[c]; }
-          if (boxqp<NU>(Quu, qu, lb, ub, xq, cm, Kc, sp.boxqp_maxiter, sp.boxqp_th_acceptstep, sp.boxqp_th_grad,
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) { xq[c] = x0[c]; Kc[c] = Qux[c]; }
+          if (boxqp<NU>(Quu, qu, lb, ub, xq, g0, cm, Kc, sp.boxqp_maxiter, sp.boxqp_th_acceptstep, sp.boxqp_th_grad,
                         sp.boxqp_reg)) failed = true;
           ASLR_UNROLL for (int c = 0; c < NU; ++c) {
             kv[c] = -xq[c];
             if (cm[c]) qu[c] = 0.0;
           }
+        }
+      }
+      if (C::DMA) {
+        ASLR_UNROLL for (int r = 0; r < NX; ++r) fg[r] = 0.0;
+        if (gaps_on) {
+          ASLR_UNROLL for (int r = 0; r < NX; ++r) fg[r] = auxT[2 * NU + r];
         }
       }
       double Quuk[NU];
