@@ -16,6 +16,21 @@
 
 namespace aslr {
 
+// Region timing of the sweep (build with -DASLR_BWD_PROFILE; tools/bwd_regions.py): every wave adds the shader-clock
+// cycles it spent between consecutive marks to a device-side table.  Compiled out of the product library.
+#ifdef ASLR_BWD_PROFILE
+static __device__ unsigned long long aslr_bwd_prof_dev[32];
+#define ASLR_PROF_DECL long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = clock64()
+#define ASLR_PROF(i) do { const long long now_ = clock64(); prof_acc[i] += now_ - prof_last; prof_last = now_; } while (0)
+#define ASLR_PROF_COUNT(i) do { prof_acc[i] += 1; } while (0)
+#define ASLR_PROF_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&aslr_bwd_prof_dev[i_], (unsigned long long)prof_acc[i_]); } } while (0)
+#else
+#define ASLR_PROF_DECL
+#define ASLR_PROF(i)
+#define ASLR_PROF_COUNT(i)
+#define ASLR_PROF_FLUSH
+#endif
+
 // Cholesky with reciprocal pivots from rsqrt: L (lower, in place), rinv[i] = 1 / L[i][i].
 // Returns true on a non-positive (or NaN) pivot, like Eigen::LLT info() != Success.
 template <int N>
@@ -55,7 +70,11 @@ ASLR_DEV bool chol_rs(double (&A)[N][N], double (&rinv)[N]) {
 template <int NU>
 ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const double (&lb)[NU],
                     const double (&ub)[NU], double (&x)[NU], double (&g)[NU], bool (&cm)[NU], double (&kcol)[NU],
-                    int boxqp_maxiter, double th_acceptstep, double th_grad, double reg) {
+                    int boxqp_maxiter, double th_acceptstep, double th_grad, double reg
+#ifdef ASLR_BWD_PROFILE
+                    , long long (&prof_acc)[16], long long &prof_last
+#endif
+                    ) {
   bool bad = false, finished = false;
   double mk[NU], mkL[NU], L[NU][NU], rinv[NU];
   ASLR_UNROLL for (int i = 0; i < NU; ++i) {
@@ -77,7 +96,9 @@ ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const doub
     ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
     fold += 0.5 * x[i] * s + q[i] * x[i];
   }
+  ASLR_PROF(6);
   for (int it = 0; it < boxqp_maxiter; ++it) {
+    ASLR_PROF_COUNT(12);
     double gnorm = 0.0, nfree = 0.0;
     ASLR_UNROLL for (int j = 0; j < NU; ++j) {
       // (plain & / |: four compares and three mask operations, no short-circuit branches)
@@ -101,6 +122,7 @@ ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const doub
     }
     chol_solve_r<NU>(L, rinv, rhs);
     ASLR_UNROLL for (int i = 0; i < NU; ++i) dx[i] = mk[i] * (rhs[i] - x[i]);
+    ASLR_PROF(7);
     double alpha = 1.0, fnext = fold;
     bool found = !stepping;
     for (int al = 0; al < ASLR_NALPHA; ++al, alpha *= 0.5) {
@@ -128,7 +150,9 @@ ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const doub
       ASLR_UNROLL for (int j = 0; j < NU; ++j) s += H[i][j] * x[j];
       g[i] = s;
     }
+    ASLR_PROF(8);
   }
+  ASLR_PROF(7);
   // factor of the final free block: the one at hand unless the active set changed in the last step
   bool stale = false;
   ASLR_UNROLL for (int i = 0; i < NU; ++i) stale = stale || (mkL[i] != mk[i]);
@@ -140,6 +164,7 @@ ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const doub
   ASLR_UNROLL for (int i = 0; i < NU; ++i) { cm[i] = (mk[i] == 0.0); kcol[i] *= mk[i]; }
   chol_solve_r<NU>(L, rinv, kcol);
   ASLR_UNROLL for (int i = 0; i < NU; ++i) kcol[i] *= mk[i];
+  ASLR_PROF(9);
   return bad;
 }
 
@@ -193,18 +218,23 @@ struct BwdCfg {
 };
 
 typedef __attribute__((address_space(3))) void *lds_void_p;
-typedef __attribute__((address_space(3))) char *lds_char_p;
-typedef __attribute__((address_space(1))) const void *glb_void_p;
 
-// One record through LDS-DMA: piece I of every team with instruction offset I * BS * 8, which moves the global
-// address by I blocks and the LDS address by the same number of bytes (hence the DMAW - BS stride of the bases).
+// One 16-byte piece per lane from global memory straight into LDS (global_load_lds_dwordx4): lane L's piece lands at
+// LDS address m0 + OFF + 16 L.  Issued through inline assembly on purpose: for the builtin the compiler drains vmcnt
+// before EVERY later LDS read whose memory operand has lost its alias scope (all merged ds_read_b128 have), i.e.
+// right after the issue, which exposes the whole HBM latency.  The kernel orders these loads by hand instead: one
+// s_waitcnt vmcnt(0) at the top of the next knot before the first read of the target, and an lgkmcnt(0) + wave
+// barrier before the issue so no earlier read of the target is still pending.  (m0 has no other user here.)
 template <int OFF>
-ASLR_DEV void dma16(const char *g, lds_char_p l) {
-  __builtin_amdgcn_global_load_lds((glb_void_p)g, (lds_void_p)l, 16, OFF, 0);
+ASLR_DEV void dma16(const char *g, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" : : "v"(g), "s"(lds_addr), "n"(OFF) : "memory");
 }
+ASLR_DEV unsigned lds_address(const void *p) { return (unsigned)(size_t)(lds_void_p)p; }
+// One record: piece I of every team with instruction offset I * BS * 8, which moves the global address by I blocks
+// and the LDS address by the same number of bytes (hence the DMAW - BS stride of the bases).
 template <class C, int... I>
-ASLR_DEV void dma_record(const char *g, lds_char_p recD, int lt, std::integer_sequence<int, I...>) {
-  ((C::NPRE * C::TEAM == C::REC / 2 || lt + C::TEAM * I < C::REC / 2 ? dma16<I * C::BS * 8>(g, recD + I * (C::DMAW - C::BS) * 8) : (void)0), ...);
+ASLR_DEV void dma_record(const char *g, unsigned recD_addr, int lt, std::integer_sequence<int, I...>) {
+  ((C::NPRE * C::TEAM == C::REC / 2 || lt + C::TEAM * I < C::REC / 2 ? dma16<I * C::BS * 8>(g, recD_addr + I * (C::DMAW - C::BS) * 8) : (void)0), ...);
 }
 
 // BOX: SolverBoxDDP gains may be needed (solver is BoxDDP); GAPS: infeasible candidates may be present
@@ -213,7 +243,11 @@ template <int NX, int NU, int HS, int TPWA, bool BOX, bool GAPS>
 __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
   using C = BwdCfg<NX, NU, HS, TPWA>;
   constexpr int NXP = C::NXP, TEAM = C::TEAM, TPW = C::TPW, RPL = C::RPL, REC = C::REC;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  // The work arrays are a static allocation in the DMA configuration: the compiler then knows they cannot overlap
+  // the DMA targets and does not drain vmcnt before reading them while the next record is in flight.
+  extern __shared__ __attribute__((aligned(16))) double smem_dyn[];
+  __shared__ __attribute__((aligned(16))) double smem_sta[C::DMA ? C::TPW * C::LDS_TEAM : 2];
+  double *smem = C::DMA ? smem_sta : smem_dyn;
 
   const int lane = threadIdx.x, team = lane / TEAM, lt = lane % TEAM, j = lt % NXP, h = lt / NXP;
   const int B = a.B, T = a.T;
@@ -275,6 +309,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
   ASLR_UNROLL for (int c = 0; c < NU; ++c) oh_u[c] = (c == j) ? 1.0 : 0.0;
 
   double d1 = 0.0, d2 = 0.0, stop = 0.0, dgf = 0.0, dqf = 0.0;
+  ASLR_PROF_DECL;
   while (__ballot(need) != 0ull) {
     bool failed = false;
     d1 = d2 = stop = dgf = dqf = 0.0;
@@ -334,8 +369,8 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
 #define ASLR_BWD_DMA(tt)                                                                               \
     do {                                                                                               \
       const char *kb = reinterpret_cast<const char *>(a.deriv + (size_t)(tt) * B * REC); /* uniform */ \
-      dma_record<C>(kb + rec_voff, (lds_char_p)recD, lt, std::make_integer_sequence<int, C::NPRE>());  \
-      if (aux_on) __builtin_amdgcn_global_load_lds((glb_void_p)(aux_src + (size_t)(tt) * aux_step), (lds_void_p)(auxD + ((tt) & 1) * C::DMAW), 16, 0, 0); \
+      dma_record<C>(kb + rec_voff, lds_address(recD), lt, std::make_integer_sequence<int, C::NPRE>()); \
+      if (aux_on) dma16<0>(reinterpret_cast<const char *>(aux_src + (size_t)(tt) * aux_step), lds_address(auxD) + ((tt) & 1) * C::DMAW * 8); \
       pre_m = node_model_c[tt];                                                                        \
     } while (0)
     // per-lane byte offset of this lane's 16-byte piece inside a knot's slab of records (B * REC * 8 < 2^32)
@@ -350,6 +385,8 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
     if (C::DMA) ASLR_BWD_DMA(T - 1); else ASLR_BWD_PREFETCH(T - 1);
     for (int t = T - 1; t >= 0; --t) {
       const size_t tb = (size_t)t * B + b;
+      ASLR_PROF(11);
+      ASLR_PROF_COUNT(15);
       const double *auxT = auxD + (C::DMA ? (t & 1) * C::DMAW + team * C::BS : 0); // [us | k | gap] of this knot
       double ut[NU], k0[NU], fg[NX];
       if (C::DMA) {
@@ -372,6 +409,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         if (t > 0) ASLR_BWD_PREFETCH(t - 1);
       }
 
+      ASLR_PROF(0);
       // ---- step 1: A = Fx^T P (my rows of column jj), Bc = Fu^T P (column jj), Qx, Qu ----
       double Fxcol[NX], Fucol[NX];
       ASLR_UNROLL for (int l = 0; l < NX; ++l) { Fxcol[l] = R(C::oFx + l * NX, jj); Fucol[l] = R(C::oFu + l * NU, ju); }
@@ -394,6 +432,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         Qu_own = R(C::oLu, ju) + s2;
       }
       wave_sync();
+      ASLR_PROF(1);
       // ---- step 2: Qxx (my rows), Qux (column jj), Quu (column jj < NU) ----
       double Qxx[RPL], Qux[NU];
       {
@@ -418,6 +457,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       }
       wave_sync();
       ASLR_UNROLL for (int c = 0; c < NU; ++c) Qux[c] = QuxL[c * NX + jj];
+      ASLR_PROF(2);
       if (C::DMA) {
         // this knot's record is consumed: take the control inputs, then let the next knot's loads fly
         // under the gains phase
@@ -426,6 +466,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         wave_sync();
         if (t > 0) ASLR_BWD_DMA(t - 1);
       }
+      ASLR_PROF(3);
       // ---- step 3: gains (redundant per lane) ----
       double Quu[NU][NU], qu[NU], kv[NU], Kc[NU];
       ASLR_UNROLL for (int c = 0; c < NU; ++c) {
@@ -454,10 +495,12 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       }
       // plain DDP gains K = Quu^-1 Qux, k = Quu^-1 Qu: needed by unconstrained nodes and by box nodes whose
       // first active set is empty; skipped (wave-uniformly) when every team of the wave runs the QP
+      ASLR_PROF(4);
       const bool need_plain = !boxed || !any_clamped;
       bool plain_bad = false;
       ASLR_UNROLL for (int c = 0; c < NU; ++c) { kv[c] = 0.0; Kc[c] = 0.0; }
       if (__ballot(need_plain) != 0ull) {
+        ASLR_PROF_COUNT(14);
         double L[NU][NU], rinv[NU];
         ASLR_UNROLL for (int c = 0; c < NU; ++c)
           ASLR_UNROLL for (int e = 0; e < NU; ++e) L[c][e] = Quu[c][e];
@@ -466,6 +509,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         chol_solve_r<NU>(L, rinv, kv);
         chol_solve_r<NU>(L, rinv, Kc);
       }
+      ASLR_PROF(5);
       if (!boxed) {
         if (plain_bad) failed = true;
       } else {
@@ -489,14 +533,20 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
           double xq[NU];
           bool cm[NU];
           ASLR_UNROLL for (int c = 0; c < NU; ++c) { xq[c] = x0[c]; Kc[c] = Qux[c]; }
+          ASLR_PROF_COUNT(13);
           if (boxqp<NU>(Quu, qu, lb, ub, xq, g0, cm, Kc, sp.boxqp_maxiter, sp.boxqp_th_acceptstep, sp.boxqp_th_grad,
-                        sp.boxqp_reg)) failed = true;
+                        sp.boxqp_reg
+#ifdef ASLR_BWD_PROFILE
+                        , prof_acc, prof_last
+#endif
+                        )) failed = true;
           ASLR_UNROLL for (int c = 0; c < NU; ++c) {
             kv[c] = -xq[c];
             if (cm[c]) qu[c] = 0.0;
           }
         }
       }
+      ASLR_PROF(6);
       if (C::DMA) {
         ASLR_UNROLL for (int r = 0; r < NX; ++r) fg[r] = 0.0;
         if (gaps_on) {
@@ -537,6 +587,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         }
       }
       wave_sync();
+      ASLR_PROF(10);
       // ---- step 4: symmetrise (column jj of the symmetric Vxx = its row jj), gap term, publish Vx ----
       double chk = 0.0;
       ASLR_UNROLL for (int r = 0; r < NX; ++r) {
@@ -568,6 +619,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       wave_sync();
       ASLR_UNROLL for (int l = 0; l < NX; ++l) pvec[l] = VxL[l];
     }
+    ASLR_PROF(11);
     // ---- end of sweep: publish or regularise and retry ----
     if (need) {
       if (!failed) {
@@ -611,6 +663,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       }
     }
   }
+  ASLR_PROF_FLUSH;
 }
 
 // `all_feasible`: the caller knows every trajectory of the shard is feasible (no gap terms needed)
@@ -618,7 +671,7 @@ template <int NX, int NU, int HS, int TPWA = 0>
 int launch_backward_t(const KArgs &k, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st) {
   using C = BwdCfg<NX, NU, HS, TPWA>;
   const int blocks = (k.B + C::TPW - 1) / C::TPW;
-  const size_t lds = (size_t)C::TPW * C::LDS_TEAM * sizeof(double);
+  const size_t lds = C::DMA ? 0 : (size_t)C::TPW * C::LDS_TEAM * sizeof(double); // (DMA: allocated statically)
   const bool box = sd.solver == ASLR_SOLVER_BOXDDP;
   if (box && !all_feasible) hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, true, true>), dim3(blocks), dim3(64), lds, st, k, sd, lim);
   else if (box) hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, true, false>), dim3(blocks), dim3(64), lds, st, k, sd, lim);

@@ -1,0 +1,37 @@
+"""Where the cycles of the nx = 8 backward sweep go: loads the region-timing build of the library
+(`make -C aslr_to_amd/csrc prof`), runs the bench workload for a few iterations and prints the average shader-clock
+cycles per knot per wave spent in each region of the kernel.  Usage: bwd_regions.py [B] [solver]"""
+import sys, os, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from aslr_to_amd import _abi as A
+A.lib_path = lambda: os.path.join(ROOT, "tools", "ubench", "libaslr_to_hip_prof.so")
+import numpy as np, torch
+from aslr_to_amd import scenarios
+from aslr_to_amd.engine import Engine
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+solver = sys.argv[2] if len(sys.argv) > 2 else "SolverBoxDDP"
+sc = scenarios.two_dof_vsa_boxddp(B=B, T=100)
+low = scenarios.lower(sc)
+e = Engine(low)
+e.set_candidate(None, None)
+sp = scenarios.solver_params(sc, solver=solver, fixed_iterations=1)
+lib = A.load_library()
+out = (ctypes.c_ulonglong * 32)()
+for i in range(20): e.iterate(sp, i == 0)
+torch.cuda.synchronize()
+lib.aslr_debug_bwd_prof(out, 1)
+N = 30
+for i in range(N): e.iterate(sp, False)
+torch.cuda.synchronize()
+lib.aslr_debug_bwd_prof(out, 0)
+v = np.array(list(out), dtype=np.float64)
+knots = v[15]
+names = ["top: wait for the record", "step 1", "step 2", "DMA issue", "step 3 (first active set)", "plain gains",
+         "box decision + QP prologue", "QP head (mask, factor, solve)", "QP line search + gradient", "QP final gains",
+         "tail (Vx, Vxx, stores)", "step 4 + loop"]
+tot = v[:12].sum()
+print("wave-knots %d, cycles per wave-knot %.0f" % (knots, tot / knots))
+for n, c in zip(names, v[:12]): print("  %-32s %8.0f cycles  %5.1f %%" % (n, c / knots, 100 * c / tot))
+print("  QP calls per wave-knot %.3f, QP iterations per call %.3f, plain executions per wave-knot %.3f"
+      % (v[13] / knots, v[12] / max(v[13], 1), v[14] / knots))
