@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         const int idx = lt + TEAM * i;                                                                 \
         if (C::NPRE * TEAM == REC / 2 || idx < REC / 2) { const nt_double2 v2 = __builtin_nontemporal_load(src + idx); prx[i] = v2.x; pry[i] = v2.y; } \
       }                                                                                                \
-      pre_m = node_model_c[tt];                                                                        \
+      pre_m = node_model_at(a, tt);                                                                        \
       if (box) {                                                                                       \
         ASLR_UNROLL for (int c = 0; c < NU; ++c) { pre_u[c] = a.us[tbp * NU + c]; pre_k[c] = a.kff[tbp * NU + c]; } \
       }                                                                                                \
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       const char *kb = reinterpret_cast<const char *>(a.deriv + (size_t)(tt) * B * REC); /* uniform */ \
       dma_record<C>(kb + rec_voff, lds_address(recD), lt, std::make_integer_sequence<int, C::NPRE>()); \
       if (aux_on) dma16<0>(reinterpret_cast<const char *>(aux_src + (size_t)(tt) * aux_step), lds_address(auxD) + ((tt) & 1) * C::DMAW * 8); \
-      pre_m = node_model_c[tt];                                                                        \
+      pre_m = node_model_at(a, tt);                                                                        \
     } while (0)
     // per-lane byte offset of this lane's 16-byte piece inside a knot's slab of records (B * REC * 8 < 2^32)
     const unsigned rec_voff = (unsigned)b * (unsigned)(REC * 8) + (unsigned)lt * 16u;
@@ -380,8 +380,6 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
     const double *aux_src = (lt < NU / 2 ? a.us + 2 * lt : (lt < NU ? a.kff + 2 * (lt - NU / 2) : a.gaps + 2 * (lt - NU))) + (size_t)b * aux_stride;
     const size_t aux_step = (size_t)B * aux_stride; // doubles per knot
     const bool aux_on = lt < NU ? box : (gaps_on && lt < C::AUXL);
-    const int32_t __attribute__((address_space(4))) *node_model_c =
-        (const int32_t __attribute__((address_space(4))) *)(a.node_model); // read-only table: scalar loads
     if (C::DMA) ASLR_BWD_DMA(T - 1); else ASLR_BWD_PREFETCH(T - 1);
     for (int t = T - 1; t >= 0; --t) {
       const size_t tb = (size_t)t * B + b;

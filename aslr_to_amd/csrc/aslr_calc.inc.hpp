@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
   if (__ballot(compute) == 0ull) return; // wave-uniform
 
   const DevDesc &D = *a.desc;
-  const DevModel &dm = D.models[a.node_model[t]];
+  const DevModel &dm = D.models[node_model_at(a, t)];
   const double *fref = a.frame_ref ? a.frame_ref + 12 * (size_t)b : nullptr;
 
   double xnext[NX], cost = 0.0;
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64) quasi_static_kernel(KArgs a, int maxiter, 
   if (b >= B || t >= T) return;
   const size_t tb = (size_t)t * B + b;
   const DevDesc &D = *a.desc;
-  const DevModel &dm = D.models[a.node_model[t]];
+  const DevModel &dm = D.models[node_model_at(a, t)];
   const double *fref = a.frame_ref ? a.frame_ref + 12 * (size_t)b : nullptr;
   const typename CH::Consts cc(D);
   ModelRegs<NJ, NU> mr;

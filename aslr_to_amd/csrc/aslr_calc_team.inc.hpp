@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(64) dyn_team_kernel(KArgs a, int mode) {
   const DevDesc &D = *a.desc;
   const aslr_chain_t &ch = D.chain;
   const chain_cp chc = chain_const(&D.chain);
-  const DevModel &dm = D.models[a.node_model[t]];
+  const DevModel &dm = D.models[node_model_at(a, t)];
 
   // ---- x, u of this knot (from the accepted candidate when there is one; the terminal node takes u = 0) ----
   {

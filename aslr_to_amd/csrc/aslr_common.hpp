@@ -41,6 +41,12 @@ struct KArgs {
   int32_t planar; // the chain qualifies for the planar dynamics path (DevDesc::planar.ok)
 };
 
+// node -> action-model index, read through the constant address space: the table is never written by a kernel, and a
+// scalar load keeps it out of vmcnt (as a vector load its wait drained every prefetch issued just before it)
+ASLR_DEV int node_model_at(const KArgs &a, int t) {
+  return ((const int32_t __attribute__((address_space(4))) *)(a.node_model))[t];
+}
+
 // solver parameters by value
 struct SolverDev {
   int32_t solver, fixed_iterations;

@@ -925,7 +925,10 @@ ASLR_DEV void pinv_normal_solve(int rows, double (&A)[N][N], const double (&g)[N
 template <int NJ, int NU>
 struct ModelRegs {
   double dt, K[NJ][NJ], Binv[NJ][NJ], S[NJ][NU];
-  ASLR_DEV void load(const DevModel &dm) {
+  ASLR_DEV void load(const DevModel &dm_) {
+    // (constant address space: scalar loads, counted by lgkmcnt -- a vector load here made every knot of the
+    //  rollout wait for its own outstanding candidate stores)
+    const DevModel __attribute__((address_space(4))) &dm = *(const DevModel __attribute__((address_space(4))) *)(&dm_);
     dt = dm.m.dt;
     ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
       ASLR_UNROLL for (int j = 0; j < NJ; ++j) { K[i][j] = dm.m.K[i * NJ + j]; Binv[i][j] = dm.Binv[i * NJ + j]; }

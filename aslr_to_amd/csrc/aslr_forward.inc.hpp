@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
       pf[q] = 0.0;
       if (son[q] && (!sctl[q] || t < T)) pf[q] = sp0[q][(size_t)t * sstr[q]];
     }
-    mi_next = a.node_model[t];
+    mi_next = node_model_at(a, t);
   };
   prefetch(0);
   for (int t = 0; t <= T; ++t) {
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
     ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = us[i];
   }
   const DevDesc &D = *a.desc;
-  const DevModel &dm = D.models[a.node_model[t]];
+  const DevModel &dm = D.models[node_model_at(a, t)];
   const double *fref = a.frame_ref ? a.frame_ref + 12 * (size_t)b : nullptr;
   const typename CH::Consts cc(D);
   ModelRegs<NJ, NU> mr;

@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
     const size_t tb = (size_t)t * B + b;
     wave_sync(); // the previous knot's readers of the stage are done
     ASLR_UNROLL for (int q = 0; q < NSLOT; ++q) { if (lane + 64 * q < C::STG) stg[lane + 64 * q] = pf[q]; }
-    const int mi = a.node_model[t];
+    const int mi = node_model_at(a, t);
     wave_sync();
     if (t < T) prefetch(t + 1);
     if (use_gaps) {

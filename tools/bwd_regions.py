@@ -30,8 +30,11 @@ knots = v[15]
 names = ["top: wait for the record", "step 1", "step 2", "DMA issue", "step 3 (first active set)", "plain gains",
          "box decision + QP prologue", "QP head (mask, factor, solve)", "QP line search + gradient", "QP final gains",
          "tail (Vx, Vxx, stores)", "step 4 + loop"]
-tot = v[:12].sum()
+names.append("after the box branch (incl. waiting for wave mates' QP)")
+v = np.concatenate([v[:12], v[16:17], v[12:16]])
+tot = v[:13].sum()
+v = np.concatenate([v[:13], np.zeros(3), v[13:]])
 print("wave-knots %d, cycles per wave-knot %.0f" % (knots, tot / knots))
-for n, c in zip(names, v[:12]): print("  %-32s %8.0f cycles  %5.1f %%" % (n, c / knots, 100 * c / tot))
+for n, c in zip(names, v[:13]): print("  %-32s %8.0f cycles  %5.1f %%" % (n, c / knots, 100 * c / tot))
 print("  QP calls per wave-knot %.3f, QP iterations per call %.3f, plain executions per wave-knot %.3f"
-      % (v[13] / knots, v[12] / max(v[13], 1), v[14] / knots))
+      % (v[17] / knots, v[16] / max(v[17], 1), v[18] / knots))
