@@ -148,8 +148,17 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
   };
 
   // model rows of this lane (reloaded when the node's model changes; wave-uniform)
-  double Krow[NJ], Srow[NJ], Brow[NJ], dt = 0.0;
+  double Krow[NJ], Srow[NJ], Brow[NJ], dt = 0.0, lb_c = 0.0, ub_c = 0.0;
+  bool has_lim = false;
   int m_loaded = -1;
+  // joint placements and axes: constants of the chain, staged once in LDS (as global loads inside the knot loop they
+  // cost a vmcnt(0) per knot, which also waits for the prefetch issued just before; in registers they spill)
+  __shared__ double jtab[8][12];
+  if (threadIdx.x < NJ) {
+    ASLR_UNROLL for (int k = 0; k < 9; ++k) jtab[threadIdx.x][k] = ch.joint_R[threadIdx.x][k];
+    ASLR_UNROLL for (int k = 0; k < 3; ++k) jtab[threadIdx.x][9 + k] = ch.axis[threadIdx.x][k];
+  }
+  __syncthreads();
 
   // x0 into the team's state
   ASLR_UNROLL for (int k = 0; k < 4; ++k) {
@@ -189,19 +198,26 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
       ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
         Krow[j] = dm.m.K[cj * NJ + j]; Srow[j] = dm.m.S[cj * NU + j]; Brow[j] = dm.Binv[cj * NJ + j];
       }
+      has_lim = lim.has[mi] != 0;
+      lb_c = lim.lb[mi][cj];
+      ub_c = lim.ub[mi][cj];
+      // the values are consumed HERE, so the wait for these loads sits inside this rarely-taken branch and not at
+      // the join, where it would drain the prefetch of every knot
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(Krow[j]), "+v"(Srow[j]), "+v"(Brow[j]));
+      asm volatile("" : "+v"(dt), "+v"(lb_c), "+v"(ub_c));
       m_loaded = mi;
     }
     // ---- control law, row cj: u = us - alpha k - K (x - xs), box clamp ----
     {
       double s = stg[C::oU + cj] - stg[C::oKf + cj] * alpha;
       ASLR_UNROLL for (int jx = 0; jx < NX; ++jx) s -= stg[C::oK + cj * NX + jx] * (xT[jx] - stg[C::oXr + jx]);
-      if (box && lim.has[mi]) s = fmin(fmax(s, lim.lb[mi][cj]), lim.ub[mi][cj]);
+      if (box && has_lim) s = fmin(fmax(s, lb_c), ub_c);
       if (jl) uT[c] = s;
       if (team_on && jl) a.us_try[((size_t)ai * TB + tb) * NU + c] = s;
     }
     // ---- rotation of joint cj ----
     if (jl) {
-      const M3 R = mul(m3(ch.joint_R[cj]), axis_angle(v3(ch.axis[cj]), xT[cj])); // (per-lane joint: vector loads)
+      const M3 R = mul(m3(jtab[cj]), axis_angle(v3(jtab[cj] + 9), xT[cj]));
       ASLR_UNROLL for (int k = 0; k < 9; ++k) RL[9 * c + k] = R.a[k];
     }
     wave_sync();
