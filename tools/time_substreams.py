@@ -3,6 +3,9 @@ sweeps of one sub-shard overlap the throughput-bound kernels of the others).  Us
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+if os.environ.get("ASLR_LIB_OVERRIDE"):  # an experimental build of the library (tools/ubench/*.so)
+    from aslr_to_amd import _abi as _A
+    _A.lib_path = lambda: os.path.abspath(os.environ["ASLR_LIB_OVERRIDE"])
 from aslr_to_amd import scenarios
 from aslr_to_amd.engine import Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
