@@ -373,8 +373,8 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       if (aux_on) dma16<0>(reinterpret_cast<const char *>(aux_src + (size_t)(tt) * aux_step), lds_address(auxD) + ((tt) & 1) * C::DMAW * 8); \
       pre_m = node_model_at(a, tt);                                                                        \
     } while (0)
-    // per-lane byte offset of this lane's 16-byte piece inside a knot's slab of records (B * REC * 8 < 2^32)
-    const unsigned rec_voff = (unsigned)b * (unsigned)(REC * 8) + (unsigned)lt * 16u;
+    // per-lane byte offset of this lane's 16-byte piece inside a knot's slab of records
+    const size_t rec_voff = (size_t)b * (size_t)(REC * 8) + (size_t)lt * 16u;
     // which of the small inputs this lane fetches: lanes [0, nu/2) us, [nu/2, nu) k, [nu, nu + nx/2) the gap
     const size_t aux_stride = lt < NU ? NU : NX;
     const double *aux_src = (lt < NU / 2 ? a.us + 2 * lt : (lt < NU ? a.kff + 2 * (lt - NU / 2) : a.gaps + 2 * (lt - NU))) + (size_t)b * aux_stride;
