@@ -227,7 +227,7 @@ typedef __attribute__((address_space(3))) void *lds_void_p;
 // barrier before the issue so no earlier read of the target is still pending.  (m0 has no other user here.)
 template <int OFF>
 ASLR_DEV void dma16(const char *g, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" : : "v"(g), "s"(lds_addr), "n"(OFF) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2 nt" : : "v"(g), "s"(lds_addr), "n"(OFF) : "memory");
 }
 ASLR_DEV unsigned lds_address(const void *p) { return (unsigned)(size_t)(lds_void_p)p; }
 // One record: piece I of every team with instruction offset I * BS * 8, which moves the global address by I blocks
