@@ -163,6 +163,19 @@ void fill_planar(const aslr_chain_t &c, PlanarChain *pl) {
   }
   pl->gx = c.gravity[0];
   pl->gy = c.gravity[1];
+  if (c.nj == 2) { // closed-form constants of the two-link chain (ChainPlanar<2>::mass2 / nle2)
+    const double J1 = pl->izz[0] + pl->m[0] * (pl->cx[0] * pl->cx[0] + pl->cy[0] * pl->cy[0]);
+    const double J2 = pl->izz[1] + pl->m[1] * (pl->cx[1] * pl->cx[1] + pl->cy[1] * pl->cy[1]);
+    const double p2x = pl->px[1], p2y = pl->py[1];
+    pl->two[0] = J1 + J2 + pl->m[1] * (p2x * p2x + p2y * p2y);
+    pl->two[1] = J2;
+    pl->two[2] = pl->m[1] * (p2x * pl->cx[1] + p2y * pl->cy[1]);
+    pl->two[3] = pl->m[1] * (p2y * pl->cx[1] - p2x * pl->cy[1]);
+    pl->two[4] = -(pl->m[0] * pl->cy[0] + pl->m[1] * p2y);
+    pl->two[5] = pl->m[0] * pl->cx[0] + pl->m[1] * p2x;
+    pl->two[6] = -pl->m[1] * pl->cy[1];
+    pl->two[7] = pl->m[1] * pl->cx[1];
+  }
   pl->ok = 1;
 }
 

@@ -217,19 +217,6 @@ struct BwdCfg {
   static_assert(!DMA || dma_layout_ok(), "record layout does not fit the LDS-DMA blocks");
 };
 
-typedef __attribute__((address_space(3))) void *lds_void_p;
-
-// One 16-byte piece per lane from global memory straight into LDS (global_load_lds_dwordx4): lane L's piece lands at
-// LDS address m0 + OFF + 16 L.  Issued through inline assembly on purpose: for the builtin the compiler drains vmcnt
-// before EVERY later LDS read whose memory operand has lost its alias scope (all merged ds_read_b128 have), i.e.
-// right after the issue, which exposes the whole HBM latency.  The kernel orders these loads by hand instead: one
-// s_waitcnt vmcnt(0) at the top of the next knot before the first read of the target, and an lgkmcnt(0) + wave
-// barrier before the issue so no earlier read of the target is still pending.  (m0 has no other user here.)
-template <int OFF>
-ASLR_DEV void dma16(const char *g, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2 nt" : : "v"(g), "s"(lds_addr), "n"(OFF) : "memory");
-}
-ASLR_DEV unsigned lds_address(const void *p) { return (unsigned)(size_t)(lds_void_p)p; }
 // One record: piece I of every team with instruction offset I * BS * 8, which moves the global address by I blocks
 // and the LDS address by the same number of bytes (hence the DMAW - BS stride of the bases).
 template <class C, int... I>

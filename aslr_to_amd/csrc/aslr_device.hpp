@@ -33,6 +33,23 @@ ASLR_DEV void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+typedef __attribute__((address_space(3))) void *lds_void_p;
+
+// One 16-byte piece per lane from global memory straight into LDS (global_load_lds_dwordx4): lane L's piece lands at
+// LDS address lds_addr + OFF + 16 L, and OFF also advances the global address.  Issued through inline assembly on
+// purpose: for the builtin the compiler drains vmcnt before EVERY later LDS read whose memory operand has lost its
+// alias scope (all merged ds_read_b128 have), i.e. right after the issue, which exposes the whole HBM latency.  The
+// kernels order these loads by hand instead: an explicit s_waitcnt vmcnt(n) before the first read of the target (n =
+// the number of vector-memory instructions issued after the loads that may still be in flight), and an lgkmcnt(0) +
+// wave barrier before the issue so that no earlier read of the target is still pending.  (m0 has no other user in
+// these kernels.)  NT: non-temporal (data read once).
+template <int OFF, bool NT = true>
+ASLR_DEV void dma16(const char *g, unsigned lds_addr) {
+  if (NT) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2 nt" : : "v"(g), "s"(lds_addr), "n"(OFF) : "memory");
+  else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" : : "v"(g), "s"(lds_addr), "n"(OFF) : "memory");
+}
+ASLR_DEV unsigned lds_address(const void *p) { return (unsigned)(size_t)(lds_void_p)p; }
+
 // sin/cos for joint angles: Cody-Waite reduction by pi/2 (33 + 53 bits of pi/2, exact for
 // |x| < ~1e5) and the fdlibm kernel polynomials; < 1 ulp there.  Larger arguments take the library
 // path.  (ocml's sincos carries the full Payne-Hanek reduction inline: ~6x the instructions.)
@@ -106,6 +123,9 @@ struct PlanarChain {
   double gx, gy;
   double cphi[ASLR_MAX_NJ], sphi[ASLR_MAX_NJ], px[ASLR_MAX_NJ], py[ASLR_MAX_NJ], pz[ASLR_MAX_NJ];
   double m[ASLR_MAX_NJ], cx[ASLR_MAX_NJ], cy[ASLR_MAX_NJ], izz[ASLR_MAX_NJ];
+  // two-link chains: constants of the closed-form joint-space inertia and nonlinear effects (ChainPlanar<2>)
+  //   [K1, J2, mA, mB, d1x, d1y, d2x, d2y], filled on the host
+  double two[8];
 };
 struct DevDesc {
   aslr_chain_t chain;
@@ -599,6 +619,7 @@ struct ChainPlanar {
   // evaluates many knots per lane does not re-fetch them every knot
   struct Consts {
     double gx, gy, cphi[NJ], sphi[NJ], px[NJ], py[NJ], pz[NJ], m[NJ], cx[NJ], cy[NJ], izz[NJ];
+    double two[8];
     SinCosK sck;
     ASLR_DEV explicit Consts(const DevDesc &D, bool loop_kernel = false) : sck(loop_kernel) {
       const PlanarChain &p = D.planar;
@@ -607,6 +628,7 @@ struct ChainPlanar {
         cphi[i] = p.cphi[i]; sphi[i] = p.sphi[i]; px[i] = p.px[i]; py[i] = p.py[i]; pz[i] = p.pz[i];
         m[i] = p.m[i]; cx[i] = p.cx[i]; cy[i] = p.cy[i]; izz[i] = p.izz[i];
       }
+      ASLR_UNROLL for (int i = 0; i < 8; ++i) two[i] = p.two[i];
     }
   };
   const Consts &pc;
@@ -647,12 +669,36 @@ struct ChainPlanar {
       if (KEEP) F_[i] = f[i];
     }
   }
+  // Two links: M(q) and the nonlinear effects in closed form (same quantities as the recursions below; about a
+  // quarter of their instructions, which matters on the serial path of the rollout).  With theta_i = phi_i + q_i,
+  // p2 / c_i the offset of joint 2 / the centres of mass, E = m2 p2 . R(theta2) c2:
+  //   M = [[K1 + 2E, J2 + E], [J2 + E, J2]],  C v = E' [ (2 v1 + v2) v2, -v1^2 ],
+  //   G2 = -(R2^T R1^T g) . m2 c2^perp,  G1 = G2 - (R1^T g) . (m1 c1^perp + m2 p2^perp).
+  ASLR_DEV void nle2(const double *v, double *out) const {
+    const double c1 = X[0].c, s1 = X[0].s, c2 = X[1].c, s2 = X[1].s;
+    const double Ep = pc.two[3] * c2 - pc.two[2] * s2;
+    const double ux = c1 * pc.gx + s1 * pc.gy, uy = c1 * pc.gy - s1 * pc.gx;
+    const double wx = c2 * ux + s2 * uy, wy = c2 * uy - s2 * ux;
+    const double G2 = -(wx * pc.two[6] + wy * pc.two[7]);
+    const double G1 = G2 - (ux * pc.two[4] + uy * pc.two[5]);
+    out[0] = Ep * ((2.0 * v[0] + v[1]) * v[1]) + G1;
+    out[1] = G2 - Ep * (v[0] * v[0]);
+  }
+  ASLR_DEV void mass2(double (&M)[NJ][NJ]) const {
+    const double E = pc.two[2] * X[1].c + pc.two[3] * X[1].s;
+    M[0][0] = pc.two[0] + 2.0 * E;
+    M[0][1] = pc.two[1] + E;
+    M[1][0] = M[0][1];
+    M[1][1] = pc.two[1];
+  }
   ASLR_DEV void nle(const double *v, double *out) {
+    if constexpr (NJ == 2) { nle2(v, out); return; }
     double zero[NJ];
     ASLR_UNROLL for (int i = 0; i < NJ; ++i) zero[i] = 0.0;
     rnea_<false>(v, zero, out);
   }
   ASLR_DEV void mass(double (&M)[NJ][NJ]) {
+    if constexpr (NJ == 2) { mass2(M); return; }
     ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
       PV ap = pv_zero();
       PV f[NJ];

@@ -50,49 +50,56 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
   const typename CH::Consts cc(D, true); // (true: this kernel loops over knots -- sin / cos constants in registers)
   ModelRegs<NJ, NU> mr;
   int m_loaded = -1;
-  // Per-knot inputs shared by the step lengths of a trajectory -- [K | xs | us | k | gaps | Vxx f] -- are loaded
-  // ONCE per team (element lt + 16 q by lane lt, one knot ahead) and staged in LDS, instead of every lane
-  // loading all of them (16 x fewer load instructions, and no K double buffer in registers).
+  // Per-knot inputs shared by the step lengths of a trajectory -- [K | xs | us | k | gaps | Vxx f] -- are fetched ONCE
+  // per team, one knot ahead, straight into LDS (global_load_lds_dwordx4: lane lt fetches the 16-byte pieces lt and
+  // lt + 16 of the list; element e of team tm lands at (e / 32) * 128 + 32 tm + e % 32 of the parity buffer).
+  // The wait for them is an explicit s_waitcnt vmcnt(NST): the candidate stores of the previous knot were issued AFTER
+  // these loads and may stay in flight -- a compiler-placed wait on prefetch registers was vmcnt(0), i.e. every knot
+  // also waited for its own candidate stores to reach memory.
   constexpr int oK = 0, oXr = oK + NU * NX, oU = oXr + NX, oKf = oU + NU, oFg = oKf + NU, oVf = oFg + NX,
-                NE = FDDP ? oVf + NX : oFg, NSLOT = (NE + TEAM - 1) / TEAM, STG = NSLOT * TEAM;
-  __shared__ double stg_all[TPW][STG];
-  double *stg = stg_all[team];
-  const double *sp0[NSLOT];
-  size_t sstr[NSLOT];
-  bool son[NSLOT], sctl[NSLOT];
-  ASLR_UNROLL for (int q = 0; q < NSLOT; ++q) {
-    const int idx = al + TEAM * q;
-    sp0[q] = a.xs; sstr[q] = 0; son[q] = false; sctl[q] = false;
-    if (idx < oXr) { sp0[q] = a.kgain + (size_t)b * NU * NX + idx; sstr[q] = (size_t)B * NU * NX; son[q] = true; sctl[q] = true; }
-    else if (idx < oU) { sp0[q] = a.xs + (size_t)b * NX + (idx - oXr); sstr[q] = (size_t)B * NX; son[q] = true; }
-    else if (idx < oKf) { sp0[q] = a.us + (size_t)b * NU + (idx - oU); sstr[q] = (size_t)B * NU; son[q] = true; sctl[q] = true; }
-    else if (idx < oFg) { sp0[q] = a.kff + (size_t)b * NU + (idx - oKf); sstr[q] = (size_t)B * NU; son[q] = true; sctl[q] = true; }
-    else if (FDDP && idx < oVf) { sp0[q] = a.gaps + (size_t)b * NX + (idx - oFg); sstr[q] = (size_t)B * NX; son[q] = need_dv; }
-    else if (FDDP && idx < oVf + NX) { sp0[q] = a.vxxf + (size_t)b * NX + (idx - oVf); sstr[q] = (size_t)B * NX; son[q] = need_dv; }
+                NE = FDDP ? oVf + NX : oFg, NPI = (NE / 2 + TEAM - 1) / TEAM, BS = 2 * TEAM, DMAW = 128;
+  static_assert(NU % 2 == 0 && NX % 2 == 0, "16-byte pieces");
+  __shared__ __attribute__((aligned(16))) double stgD[2][NPI * DMAW];
+  constexpr int NST = NX / 2 + NU / 2; // a lower bound of the store instructions per knot (16 bytes each at most)
+  const char *dsrc[NPI];
+  size_t dstr[NPI];
+  bool don[NPI], dctl[NPI];
+  ASLR_UNROLL for (int q = 0; q < NPI; ++q) {
+    const int e = 2 * (al + TEAM * q); // first element of this lane's piece
+    dsrc[q] = reinterpret_cast<const char *>(a.xs); dstr[q] = 0; don[q] = false; dctl[q] = false;
+    if (e < oXr) { dsrc[q] = reinterpret_cast<const char *>(a.kgain + (size_t)b * NU * NX + e); dstr[q] = (size_t)B * NU * NX * 8; don[q] = true; dctl[q] = true; }
+    else if (e < oU) { dsrc[q] = reinterpret_cast<const char *>(a.xs + (size_t)b * NX + (e - oXr)); dstr[q] = (size_t)B * NX * 8; don[q] = true; }
+    else if (e < oKf) { dsrc[q] = reinterpret_cast<const char *>(a.us + (size_t)b * NU + (e - oU)); dstr[q] = (size_t)B * NU * 8; don[q] = true; dctl[q] = true; }
+    else if (e < oFg) { dsrc[q] = reinterpret_cast<const char *>(a.kff + (size_t)b * NU + (e - oKf)); dstr[q] = (size_t)B * NU * 8; don[q] = true; dctl[q] = true; }
+    else if (FDDP && e < oVf) { dsrc[q] = reinterpret_cast<const char *>(a.gaps + (size_t)b * NX + (e - oFg)); dstr[q] = (size_t)B * NX * 8; don[q] = need_dv; }
+    else if (FDDP && e < oVf + NX) { dsrc[q] = reinterpret_cast<const char *>(a.vxxf + (size_t)b * NX + (e - oVf)); dstr[q] = (size_t)B * NX * 8; don[q] = need_dv; }
   }
-  double pf[NSLOT];
   int mi_next = 0;
   auto prefetch = [&](int t) {
-    ASLR_UNROLL for (int q = 0; q < NSLOT; ++q) {
-      pf[q] = 0.0;
-      if (son[q] && (!sctl[q] || t < T)) pf[q] = sp0[q][(size_t)t * sstr[q]];
+    const unsigned base = lds_address(stgD[t & 1]);
+    ASLR_UNROLL for (int q = 0; q < NPI; ++q) {
+      if (don[q] && (!dctl[q] || t < T)) dma16<0, false>(dsrc[q] + (size_t)t * dstr[q], base + q * DMAW * 8);
     }
     mi_next = node_model_at(a, t);
   };
   prefetch(0);
   for (int t = 0; t <= T; ++t) {
     const size_t tb = (size_t)t * B + b;
-    wave_sync(); // the previous knot's readers of the stage are done
-    ASLR_UNROLL for (int q = 0; q < NSLOT; ++q) stg[al + TEAM * q] = pf[q];
-    const int mi = mi_next;
+    // inputs of knot t have landed (issued one knot ago, before that knot's NST candidate stores)
+    if (t == 0) __builtin_amdgcn_s_waitcnt(0x0F70);                                             // vmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0F70 | (NST & 15) | ((NST >> 4) << 14));                  // vmcnt(NST)
     wave_sync();
-    if (t < T) prefetch(t + 1); // in flight while knot t computes
+    const double *stgT = stgD[t & 1] + team * BS;
+    auto S = [&](int e) -> double { return stgT[(e / BS) * DMAW + e % BS]; };
+    const int mi = mi_next;
+    if (t < T) prefetch(t + 1); // in flight while knot t computes (the other parity buffer: its readers finished
+                                // before the wave_sync above)
     double dx[NX];
-    if (use_gaps) { ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = x[i] + stg[oFg + i] * (alpha - 1.0); }
-    ASLR_UNROLL for (int i = 0; i < NX; ++i) dx[i] = x[i] - stg[oXr + i];
+    if (use_gaps) { ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = x[i] + S(oFg + i) * (alpha - 1.0); }
+    ASLR_UNROLL for (int i = 0; i < NX; ++i) dx[i] = x[i] - S(oXr + i);
     if (need_dv) { // dv -= fs . Vxx (xs - xs_try)
       double s = 0.0;
-      ASLR_UNROLL for (int i = 0; i < NX; ++i) s += stg[oVf + i] * (stg[oXr + i] - x[i]);
+      ASLR_UNROLL for (int i = 0; i < NX; ++i) s += S(oVf + i) * (S(oXr + i) - x[i]);
       dv -= s;
     }
     if (lane_on) {
@@ -102,8 +109,8 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
     if (t == T) break;
     double u[NU];
     ASLR_UNROLL for (int i = 0; i < NU; ++i) {
-      double s = stg[oU + i] - stg[oKf + i] * alpha;
-      ASLR_UNROLL for (int jx = 0; jx < NX; ++jx) s -= stg[oK + i * NX + jx] * dx[jx];
+      double s = S(oU + i) - S(oKf + i) * alpha;
+      ASLR_UNROLL for (int jx = 0; jx < NX; ++jx) s -= S(oK + i * NX + jx) * dx[jx];
       u[i] = s;
     }
     const int m_now = mi;
