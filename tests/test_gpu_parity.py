@@ -279,6 +279,45 @@ def test_solve_matches_oracle_on_a_larger_batch(oracle):
     assert dx < 1e-6 and du < 1e-6 and dc < 1e-4
 
 
+@pytest.mark.parametrize("name,solver", [("two_dof_vsa_boxddp", "SolverBoxDDP"), ("two_dof_sea", "SolverDDP")])
+def test_large_shard_kernel_variants_match_oracle(oracle, name, solver):
+    """Large shards: a short-horizon batch of 2051 trajectories (not a multiple of the 4 teams of a wave) over the first
+    iterations of a cold start, and two iterations at 8200 trajectories, where the launcher picks the backward sweep
+    with one lane set per column (HS = 1), against the oracle."""
+    import os
+    nth = min(16, len(os.sched_getaffinity(0)))
+    sc = scenarios.SCENARIOS[name](B=2051, T=12, seed=5)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc, solver=solver, maxiter=8)
+    ref = oracle.solve(low, sp, nthreads=nth)
+    e = _engine(low)
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=0)
+    _sync()
+    # (the "a line-search trial overflowed" note is left out of the comparison: whether a run-away trial -- rejected
+    #  either way -- crosses 1e30 within the horizon depends on the last bits of the dynamics; here it differs for
+    #  one trajectory of 2051 whose accepted iterates agree to 1e-10)
+    keep = ~np.int32(_abi.ST_FORWARD_ERR)
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER])
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)) & keep, ref["traj_i"][_abi.TI_STATUS] & keep)
+    scale = np.maximum(1.0, np.abs(ref["xs"]).max(axis=(0, 2)))
+    assert (np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max(axis=(0, 2)) < 1e-6 * scale).all()
+    uscale = np.maximum(1.0, np.abs(ref["us"]).max(axis=(0, 2)))
+    assert (np.abs(_np(e.region(_abi.R_US)) - ref["us"]).max(axis=(0, 2)) < 1e-6 * uscale).all()
+    # one iteration at a batch that selects the HS = 1 backward sweep
+    sc = scenarios.SCENARIOS[name](B=8200, T=6, seed=6)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc, solver=solver, maxiter=2)
+    ref = oracle.solve(low, sp, nthreads=nth)
+    e = _engine(low)
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=0)
+    _sync()
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)) & keep, ref["traj_i"][_abi.TI_STATUS] & keep)
+    scale = np.maximum(1.0, np.abs(ref["xs"]).max(axis=(0, 2)))
+    assert (np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max(axis=(0, 2)) < 1e-6 * scale).all()
+
+
 @pytest.mark.parametrize("name,kw,solver,maxiter", [
     ("double_pendulum", dict(T=100), "SolverDDP", 15),        # C1 as BASELINE.json states it (T = 100, SolverDDP)
     ("double_pendulum", dict(T=100), "SolverFDDP", 15),
