@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       double ut[NU], k0[NU], fg[NX];
       if (C::DMA) {
         // the record of this knot (issued during the previous one) has landed
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+        wait_vmcnt<0>();
         wave_sync();
       } else {
         // stage the record in LDS, take this knot's small inputs, start the next loads
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         // this knot's record is consumed: take the control inputs, then let the next knot's loads fly
         // under the gains phase
         ASLR_UNROLL for (int c = 0; c < NU; ++c) { ut[c] = auxT[c]; k0[c] = auxT[NU + c]; } // (used by box nodes only)
-        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): every LDS read of the record has returned
+        wait_lgkmcnt0(); // every LDS read of the record has returned
         wave_sync();
         if (t > 0) ASLR_BWD_DMA(t - 1);
       }

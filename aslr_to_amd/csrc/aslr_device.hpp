@@ -49,6 +49,14 @@ ASLR_DEV void dma16(const char *g, unsigned lds_addr) {
   else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" : : "v"(g), "s"(lds_addr), "n"(OFF) : "memory");
 }
 ASLR_DEV unsigned lds_address(const void *p) { return (unsigned)(size_t)(lds_void_p)p; }
+// s_waitcnt with only one counter constrained (gfx9 encoding: vmcnt in bits [3:0] and [15:14], expcnt [6:4],
+// lgkmcnt [11:8]; the unconstrained fields hold their maxima)
+template <int N>
+ASLR_DEV void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+ASLR_DEV void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 
 // sin/cos for joint angles: Cody-Waite reduction by pi/2 (33 + 53 bits of pi/2, exact for
 // |x| < ~1e5) and the fdlibm kernel polynomials; < 1 ulp there.  Larger arguments take the library

@@ -86,8 +86,7 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
   for (int t = 0; t <= T; ++t) {
     const size_t tb = (size_t)t * B + b;
     // inputs of knot t have landed (issued one knot ago, before that knot's NST candidate stores)
-    if (t == 0) __builtin_amdgcn_s_waitcnt(0x0F70);                                             // vmcnt(0)
-    else __builtin_amdgcn_s_waitcnt(0x0F70 | (NST & 15) | ((NST >> 4) << 14));                  // vmcnt(NST)
+    if (t == 0) wait_vmcnt<0>(); else wait_vmcnt<NST>();
     wave_sync();
     const double *stgT = stgD[t & 1] + team * BS;
     auto S = [&](int e) -> double { return stgT[(e / BS) * DMAW + e % BS]; };
