@@ -20,10 +20,10 @@ namespace aslr {
 // cycles it spent between consecutive marks to a device-side table.  Compiled out of the product library.
 #ifdef ASLR_BWD_PROFILE
 static __device__ unsigned long long aslr_bwd_prof_dev[32];
-#define ASLR_PROF_DECL long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = clock64()
+#define ASLR_PROF_DECL long long prof_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = clock64()
 #define ASLR_PROF(i) do { const long long now_ = clock64(); prof_acc[i] += now_ - prof_last; prof_last = now_; } while (0)
 #define ASLR_PROF_COUNT(i) do { prof_acc[i] += 1; } while (0)
-#define ASLR_PROF_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&aslr_bwd_prof_dev[i_], (unsigned long long)prof_acc[i_]); } } while (0)
+#define ASLR_PROF_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 20; ++i_) atomicAdd(&aslr_bwd_prof_dev[i_], (unsigned long long)prof_acc[i_]); } } while (0)
 #else
 #define ASLR_PROF_DECL
 #define ASLR_PROF(i)
@@ -72,7 +72,7 @@ ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const doub
                     const double (&ub)[NU], double (&x)[NU], double (&g)[NU], bool (&cm)[NU], double (&kcol)[NU],
                     int boxqp_maxiter, double th_acceptstep, double th_grad, double reg
 #ifdef ASLR_BWD_PROFILE
-                    , long long (&prof_acc)[16], long long &prof_last
+                    , long long (&prof_acc)[20], long long &prof_last
 #endif
                     ) {
   bool bad = false, finished = false;
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
           }
         }
       }
-      ASLR_PROF(6);
+      ASLR_PROF(16); // (a team that sits out the QP of its wave mates spends their QP time here)
       if (C::DMA) {
         ASLR_UNROLL for (int r = 0; r < NX; ++r) fg[r] = 0.0;
         if (gaps_on) {
