@@ -3,13 +3,18 @@ the box's host cores.  Usage: parity_sweep.py [B]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+if os.environ.get("ASLR_LIB_OVERRIDE"):  # an experimental / earlier build of the library
+    from aslr_to_amd import _abi as _A
+    _A.lib_path = lambda: os.path.abspath(os.environ["ASLR_LIB_OVERRIDE"])
 from aslr_to_amd import scenarios, _abi as A
 from aslr_to_amd.engine import Engine
 from oracle import pyoracle as po
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ONLY = sys.argv[2] if len(sys.argv) > 2 else None  # restrict to one scenario name
 nth = min(16, len(os.sched_getaffinity(0)))
 for name, solver, T in (("two_dof_vsa_boxddp", "SolverBoxDDP", 100), ("two_dof_sea", "SolverDDP", 100),
                         ("two_dof_sea", "SolverFDDP", 100), ("talos_arm_sea", "SolverFDDP", 40)):
+    if ONLY and name != ONLY: continue
     Bn = B if "talos" not in name else max(8, B // 16)
     sc = scenarios.SCENARIOS[name](B=Bn, T=T, seed=3)
     low = scenarios.lower(sc)
