@@ -34,9 +34,11 @@ struct BwdBlk {
                        oLuu = oLxu + NX * NU, oLx = oLuu + NU * NU, oLu = oLx + NX;
   static constexpr int even(int v) { return (v + 1) / 2 * 2; }
   // LDS arrays (doubles); every base is even (16-byte aligned)
-  static constexpr int sRec = 0, sPT = sRec + even(REC), sA = sPT + NX * NX, sB = sA + NX * NX,
+  // Vx sits directly behind PT: it is row nx of the left operand of the MFMA pass 1, which then yields Fx^T Vx and
+  // Fu^T Vx (for Qx, Qu) along with P Fx and P Fu
+  static constexpr int sRec = 0, sPT = sRec + even(REC), sVx = sPT + NX * NX, sA = sVx + even(NX), sB = sA + NX * NX,
                        sQux = sB + even(NU * NX), sQuxT = sQux + even(NU * NX), sK = sQuxT + NX * 8,
-                       sQuu = sK + even(NU * NX), sQu = sQuu + 64, sQx = sQu + 8, sVx = sQx + 32, sF = sVx + 32,
+                       sQuu = sK + even(NU * NX), sQu = sQuu + 64, sQx = sQu + 8, sF = sQx + 32,
                        sRed = sF + 32, sCost = sRed + 64, sFlag = sCost + NT, sEnd = sFlag + 2;
   static constexpr int LDS = even(sEnd);
 };
@@ -161,9 +163,12 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
       }                                                                                                \
       if (gaps_on && tid < NX) pre_f = a.gaps[tbp * NX + tid];                                         \
     } while (0)
+    ASLR_PROF_DECL;
     ASLR_BLK_PREFETCH(T - 1);
     for (int t = T - 1; t >= 0; --t) {
       const size_t tb = (size_t)t * B + b;
+      ASLR_PROF(6);
+      ASLR_PROF_COUNT(15);
       __syncthreads(); // every reader of the previous knot's record is done; PT / VxL of this knot are written
       {
         double2 *dst = reinterpret_cast<double2 *>(rec);
@@ -174,6 +179,7 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
         if (gaps_on && tid < NX) FL[tid] = pre_f;
       }
       __syncthreads();
+      ASLR_PROF(0);
       if (t > 0) ASLR_BLK_PREFETCH(t - 1);
 
       double bfx[2][MFMA ? NKS : 1]; // MFMA: the Fx operand fragments, reused by the second product
@@ -198,6 +204,14 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
             if (16 + li < NX) AL[(16 + li) * NX + rw] = c1[q];
             if (li < NU) BL[li * NX + rw] = cu[q];
           }
+        }
+        // row nx of the left operand is Vx: its results are Fx^T Vx (two column tiles) and Fu^T Vx -- the same
+        // products, summed in the same order, as the loops of the vector path below
+        static_assert(NX % 16 == 12, "row nx = 16 + 12: wave 1, lanes lk = 0, result register 3");
+        if (wv == 1 && lk == 0) {
+          QxL[li] = rec[C::oLx + li] + c0[3];
+          if (16 + li < NX) QxL[16 + li] = rec[C::oLx + 16 + li] + c1[3];
+          if (li < NU) QuL[li] = rec[C::oLu + li] + cu[3];
         }
       } else {
       // ---- pass 1: C(r, 4g..) = sum_l P(r,l) Fx(l, 4g..)  [= A(4g.., r)],  (P Fu)(r, g) [= B(g, r)] ----
@@ -224,7 +238,8 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
           }
         }
       }
-      if (tid < NX) { // Qx = Lx + Fx^T Vx, Qu = Lu + Fu^T Vx (wave 0)
+      if (MFMA) {
+      } else if (tid < NX) { // Qx = Lx + Fx^T Vx, Qu = Lu + Fu^T Vx (wave 0)
         double s = 0.0;
         ASLR_UNROLL for (int l = 0; l < NX; ++l) s += rec[C::oFx + l * NX + tid] * VxL[l];
         QxL[tid] = rec[C::oLx + tid] + s;
@@ -234,6 +249,7 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
         QuL[tid - NX] = rec[C::oLu + (tid - NX)] + s;
       }
       __syncthreads();
+      ASLR_PROF(1);
       // ---- pass 2a: Qxx = Lxx + A Fx ----
       double qxx[2][4]; // vector path: rows row[h], columns 4g..; MFMA path: column tile ct, rows 16 wv + lk + 4 q
       if constexpr (MFMA) {
@@ -270,7 +286,29 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
           qxx[h][0] = la.x + c[h][0]; qxx[h][1] = la.y + c[h][1]; qxx[h][2] = lb2.x + c[h][2]; qxx[h][3] = lb2.y + c[h][3];
         }
       }
-      // ---- pass 2b: entries tid and tid + NT of [Qux | Quu] ----
+      ASLR_PROF(2);
+      // ---- pass 2b: [Qux | Quu] = [Lxu^T | Luu] + B [Fx | Fu] ----
+      if constexpr (MFMA) {
+        // B = (P Fu)^T is the left operand (rows >= nu read neighbouring LDS: unused results); wave w takes column tile w
+        // of Qux with the Fx fragments it already holds, wave 1 also Quu
+        double4_t x0 = {0.0, 0.0, 0.0, 0.0}, u0 = x0;
+        const double *brow = BL + li * NX + lk;
+        ASLR_UNROLL for (int ks = 0; ks < NKS; ++ks) {
+          const double pa = brow[4 * ks];
+          x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, wv ? bfx[1][ks] : bfx[0][ks], x0, 0, 0, 0);
+          if (wv == 1) u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, rec[C::oFu + (4 * ks + lk) * NU + li], u0, 0, 0, 0);
+        }
+        const int col = 16 * wv + li;
+        ASLR_UNROLL for (int q = 0; q < 4; ++q) {
+          const int gq = lk + 4 * q;
+          if (gq < NU && col < NX) {
+            const double v = rec[C::oLxu + col * NU + gq] + x0[q];
+            QuxL[gq * NX + col] = v;
+            QuxT[col * 8 + gq] = v;
+          }
+          if (wv == 1 && gq < NU && li < NU) QuuL[gq * NU + li] = rec[C::oLuu + gq * NU + li] + u0[q] + (gq == li ? xr : 0.0);
+        }
+      } else {
       {
         double s = 0.0;
         const double2 *brow = reinterpret_cast<const double2 *>(BL + k2a * NX);
@@ -304,7 +342,9 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
         }
         QuuL[k3 * NU + c3] = rec[C::oLuu + k3 * NU + c3] + s + (k3 == c3 ? xr : 0.0);
       }
+      }
       __syncthreads();
+      ASLR_PROF(3);
       // ---- gains (wave 0): K = Quu^-1 Qux (one column per lane), k = Quu^-1 Qu, Quu k, Vx, d1, d2, stop ----
       if (wave0) {
         double L[NU][NU], rinv[NU], qu[NU], kv[NU], Kc[NU], Quuk[NU];
@@ -336,6 +376,7 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
       }
       __syncthreads();
       if (FlagL[0]) { failed = true; break; } // block-uniform
+      ASLR_PROF(4);
       // ---- Vxx (unsymmetrised, state regularisation on the diagonal), K to HBM ----
       {
         if constexpr (MFMA) {
@@ -385,6 +426,7 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
         if (tid + NT < NU * NX) a.kgain[tb * NU * NX + tid + NT] = KL[tid + NT];
       }
       __syncthreads();
+      ASLR_PROF(5);
       // ---- symmetrise into PT, NaN / Inf / >= 1e30 test ("backward_error") ----
       bool bad = false;
       double2 pa[2], pb[2];
@@ -428,6 +470,8 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
       if (tid < NX) VxL[tid] = Vx_own;
     }
 #undef ASLR_BLK_PREFETCH
+    ASLR_PROF(6);
+    ASLR_PROF_FLUSH;
     // ---- end of sweep: publish or regularise and retry ----
     if (!failed) {
       if (fddp) { // per-column gap terms summed in column order by one thread
