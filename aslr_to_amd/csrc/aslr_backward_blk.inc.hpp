@@ -38,7 +38,7 @@ struct BwdBlk {
   // Fu^T Vx (for Qx, Qu) along with P Fx and P Fu
   static constexpr int sRec = 0, sPT = sRec + even(REC), sVx = sPT + NX * NX, sA = sVx + even(NX), sB = sA + NX * NX,
                        sQux = sB + even(NU * NX), sQuxT = sQux + even(NU * NX), sK = sQuxT + NX * 8,
-                       sQuu = sK + even(NU * NX), sQu = sQuu + 64, sQx = sQu + 8, sF = sQx + 32,
+                       sQuu = sK + 8 * NX, sQu = sQuu + 64, sQx = sQu + 8, sF = sQx + 32,
                        sRed = sF + 32, sCost = sRed + 64, sFlag = sCost + NT, sEnd = sFlag + 2;
   static constexpr int LDS = even(sEnd);
 };
@@ -99,6 +99,11 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
     }
   }
   if (done) return;
+  // zero padding of the 8-long contraction of the MFMA Vxx update (never overwritten: Qux^T and K hold nu < 8 entries)
+  static_assert(NU < 8, "one padding slot per row");
+  ASLR_UNROLL for (int c = NU; c < 8; ++c) {
+    if (tid < NX) { QuxT[tid * 8 + c] = 0.0; KL[c * NX + tid] = 0.0; }
+  }
   bool need = true;
   double xreg = TF[ASLR_TF_XREG * B + b];
   const bool fddp = GAPS && sp.solver == ASLR_SOLVER_FDDP;
@@ -380,18 +385,18 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
       // ---- Vxx (unsymmetrised, state regularisation on the diagonal), K to HBM ----
       {
         if constexpr (MFMA) {
-          double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, k8[4][8];
-          ASLR_UNROLL for (int q = 0; q < 4; ++q) {
-            const int rw = 16 * wv + lk + 4 * q;
-            const double2 *qt = reinterpret_cast<const double2 *>(QuxT + (rw < NX ? rw : NX - 1) * 8);
-            ASLR_UNROLL for (int c = 0; c < 8; c += 2) { const double2 v = qt[c / 2]; k8[q][c] = v.x; k8[q][c + 1] = v.y; }
+          // Qux^T K on the matrix unit too: contraction over the nu controls, padded to 8 with the zeros set at the top
+          // (rows / columns >= nx read neighbouring LDS: unused results)
+          double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0;
+          const double *qrow = QuxT + (16 * wv + li) * 8 + lk;
+          ASLR_UNROLL for (int ks = 0; ks < 2; ++ks) {
+            const double pa = qrow[4 * ks];
+            const double *krow = KL + (4 * ks + lk) * NX + li;
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, krow[0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, krow[16], a1, 0, 0, 0);
           }
-          const int cl[2] = {li, 16 + li < NX ? 16 + li : NX - 1};
-          ASLR_UNROLL for (int c = 0; c < NU; ++c) {
-            const double kc[2] = {KL[c * NX + cl[0]], KL[c * NX + cl[1]]};
-            ASLR_UNROLL for (int ct = 0; ct < 2; ++ct)
-              ASLR_UNROLL for (int q = 0; q < 4; ++q) acc[ct][q] += k8[q][c] * kc[ct];
-          }
+          double acc[2][4];
+          ASLR_UNROLL for (int q = 0; q < 4; ++q) { acc[0][q] = a0[q]; acc[1][q] = a1[q]; }
           ASLR_UNROLL for (int ct = 0; ct < 2; ++ct)
             ASLR_UNROLL for (int q = 0; q < 4; ++q) {
               const int rw = 16 * wv + lk + 4 * q, cw = 16 * ct + li;
