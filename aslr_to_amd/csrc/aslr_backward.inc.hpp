@@ -16,21 +16,6 @@
 
 namespace aslr {
 
-// Region timing of the sweep (build with -DASLR_BWD_PROFILE; tools/bwd_regions.py): every wave adds the shader-clock
-// cycles it spent between consecutive marks to a device-side table.  Compiled out of the product library.
-#ifdef ASLR_BWD_PROFILE
-static __device__ unsigned long long aslr_bwd_prof_dev[32];
-#define ASLR_PROF_DECL long long prof_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = clock64()
-#define ASLR_PROF(i) do { const long long now_ = clock64(); prof_acc[i] += now_ - prof_last; prof_last = now_; } while (0)
-#define ASLR_PROF_COUNT(i) do { prof_acc[i] += 1; } while (0)
-#define ASLR_PROF_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 20; ++i_) atomicAdd(&aslr_bwd_prof_dev[i_], (unsigned long long)prof_acc[i_]); } } while (0)
-#else
-#define ASLR_PROF_DECL
-#define ASLR_PROF(i)
-#define ASLR_PROF_COUNT(i)
-#define ASLR_PROF_FLUSH
-#endif
-
 // Cholesky with reciprocal pivots from rsqrt: L (lower, in place), rinv[i] = 1 / L[i][i].
 // Returns true on a non-positive (or NaN) pivot, like Eigen::LLT info() != Success.
 template <int N>

@@ -33,6 +33,21 @@ ASLR_DEV void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Region timing of the serial sweeps (build with -DASLR_BWD_PROFILE; tools/bwd_regions*.py, tools/fwd_regions_c5.py): every wave adds the shader-clock
+// cycles it spent between consecutive marks to a device-side table.  Compiled out of the product library.
+#ifdef ASLR_BWD_PROFILE
+static __device__ unsigned long long aslr_bwd_prof_dev[32];
+#define ASLR_PROF_DECL long long prof_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = clock64()
+#define ASLR_PROF(i) do { const long long now_ = clock64(); prof_acc[i] += now_ - prof_last; prof_last = now_; } while (0)
+#define ASLR_PROF_COUNT(i) do { prof_acc[i] += 1; } while (0)
+#define ASLR_PROF_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 20; ++i_) atomicAdd(&aslr_bwd_prof_dev[i_], (unsigned long long)prof_acc[i_]); } } while (0)
+#else
+#define ASLR_PROF_DECL
+#define ASLR_PROF(i)
+#define ASLR_PROF_COUNT(i)
+#define ASLR_PROF_FLUSH
+#endif
+
 typedef __attribute__((address_space(3))) void *lds_void_p;
 
 // One 16-byte piece per lane from global memory straight into LDS (global_load_lds_dwordx4): lane L's piece lands at

@@ -167,9 +167,12 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
   }
   double dv = 0.0;
   bool fail = false;
+  ASLR_PROF_DECL;
   prefetch(0);
   for (int t = 0; t <= T; ++t) {
     const size_t tb = (size_t)t * B + b;
+    ASLR_PROF(7);
+    ASLR_PROF_COUNT(15);
     wave_sync(); // the previous knot's readers of the stage are done
     ASLR_UNROLL for (int q = 0; q < NSLOT; ++q) { if (lane + 64 * q < C::STG) stg[lane + 64 * q] = pf[q]; }
     const int mi = node_model_at(a, t);
@@ -207,6 +210,7 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
       asm volatile("" : "+v"(dt), "+v"(lb_c), "+v"(ub_c));
       m_loaded = mi;
     }
+    ASLR_PROF(0);
     // ---- control law, row cj: u = us - alpha k - K (x - xs), box clamp ----
     {
       double s = stg[C::oU + cj] - stg[C::oKf + cj] * alpha;
@@ -215,12 +219,14 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
       if (jl) uT[c] = s;
       if (team_on && jl) a.us_try[((size_t)ai * TB + tb) * NU + c] = s;
     }
+    ASLR_PROF(1);
     // ---- rotation of joint cj ----
     if (jl) {
       const M3 R = mul(m3(jtab[cj]), axis_angle(v3(jtab[cj] + 9), xT[cj]));
       ASLR_UNROLL for (int k = 0; k < 9; ++k) RL[9 * c + k] = R.a[k];
     }
     wave_sync();
+    ASLR_PROF(2);
     // ---- coupling and motor torques, entry cj ----
     if (jl) {
       double s = 0.0, s2 = 0.0;
@@ -228,6 +234,7 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
       tcL[c] = s;
       tmL[c] = s2;
     }
+    ASLR_PROF(3);
     // ---- one RNEA per lane: column c of M (lanes c < NJ), nonlinear effects (lane NJ) ----
     if (c <= NJ) {
       double vv[NJ], aa[NJ], tau[NJ];
@@ -239,6 +246,7 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
       ASLR_UNROLL for (int i = 0; i < NJ; ++i) ML[8 * c + i] = tau[i];
     }
     wave_sync();
+    ASLR_PROF(4);
     // ---- column cj of M^-1 (M symmetrised like Chain3D::mass) ----
     {
       double Ms[NJ][NJ], e[NJ];
@@ -251,6 +259,7 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
       if (jl) { ASLR_UNROLL for (int i = 0; i < NJ; ++i) MiL[8 * c + i] = e[i]; }
     }
     wave_sync();
+    ASLR_PROF(5);
     // ---- accelerations and semi-implicit Euler, entries cj of q_l, q_m, v_l, v_m ----
     {
       double al = 0.0, am = 0.0;
@@ -267,6 +276,8 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
       if (jl) { xT[c] = nql; xT[NJ + c] = nqm; xT[2 * NJ + c] = nvl; xT[3 * NJ + c] = nvm; }
     }
   }
+  ASLR_PROF(6);
+  ASLR_PROF_FLUSH;
   if (team_on && c == 0) {
     TI[(ASLR_TI_TRYFAIL0 + ai) * B + b] = fail ? 1 : 0;
     TF[(ASLR_TF_DVTRY0 + ai) * B + b] = dv;
