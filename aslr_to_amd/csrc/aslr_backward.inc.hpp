@@ -5,7 +5,8 @@
 // nx-column matrix.  Vxx / Vx of the next knot live in registers (each lane holds the whole column j
 // of the symmetric Vxx, which is also its row j); products stream one operand from LDS as a
 // broadcast row and keep the other in registers.  The per-knot DERIV record, the box-QP inputs and
-// the gap vector of knot t-1 are prefetched into registers while knot t computes.
+// the gap vector of knot t-1 arrive while knot t computes: at nx = 8 with two lane sets per column straight
+// into LDS (global_load_lds, issued once this knot's record is consumed), otherwise through prefetch registers.
 //
 // The kernel is bound by the instruction stream of ONE wave per SIMD (B = 4096 gives 1024 waves of
 // 4 teams), so the code avoids selects / clamps / divisions in the loop: rows divide evenly for

@@ -2,7 +2,8 @@
 //
 //   rollout_kernel     16-lane team per trajectory, lane a rolls out step length 2^-a: ONLY the serial
 //                      part stays on the T-step dependency chain (control law u = us - alpha k - K dx,
-//                      box clamp, dynamics, Euler step); every lane stores its candidate XS_TRY[a], US_TRY[a].
+//                      box clamp, dynamics, Euler step); every lane stores its candidate XS_TRY[a], US_TRY[a];
+//                      the inputs shared by the step lengths arrive per team through LDS-DMA, one knot ahead.
 //   trial_cost_kernel  one lane per (alpha, knot, trajectory): the cost stack on the stored candidates,
 //                      embarrassingly parallel (the frame-placement log map is half of a knot evaluation
 //                      and does not feed the state recursion).
