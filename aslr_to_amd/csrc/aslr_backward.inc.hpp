@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         bool interior = !any_clamped && !plain_bad && sp.boxqp_reg == 0.0;
         ASLR_UNROLL for (int c = 0; c < NU; ++c) {
           const double dlt = -kv[c], mrg = 1e-9 * (1.0 + fabs(dlt));
-          interior = interior && (dlt > lb[c] + mrg) && (dlt < ub[c] - mrg);
+          interior = interior & (dlt > lb[c] + mrg) & (dlt < ub[c] - mrg); // (plain &: no short-circuit branches)
         }
         if (!any_clamped && !plain_bad && sp.boxqp_reg == 0.0 && gnorm0 <= sp.boxqp_th_grad) {
           ASLR_UNROLL for (int c = 0; c < NU; ++c) kv[c] = -x0[c]; // (a)
