@@ -96,8 +96,8 @@ void carve(const aslr_problem_desc_t *d, int nx, int nu, aslr_region_t *r, int64
   sizes[ASLR_R_QU] = T * B * nu * D;
   sizes[ASLR_R_VX] = T1 * B * nx * D;
   sizes[ASLR_R_VXX] = T1 * B * nx * nx * D;
-  sizes[ASLR_R_XS_TRY] = (int64_t)ASLR_NALPHA * T1 * B * nx * D;
-  sizes[ASLR_R_US_TRY] = (int64_t)ASLR_NALPHA * T * B * nu * D;
+  sizes[ASLR_R_XS_TRY] = (int64_t)ASLR_NALPHA * T1 * ASLR_CAND_SLAB(B, nx) * D;
+  sizes[ASLR_R_US_TRY] = (int64_t)ASLR_NALPHA * T * ASLR_CAND_SLAB(B, nu) * D;
   sizes[ASLR_R_TRAJ_F] = (int64_t)ASLR_TF_COUNT * B * D;
   sizes[ASLR_R_TRAJ_I] = (int64_t)ASLR_TI_COUNT * B * sizeof(int32_t);
   sizes[ASLR_R_X0] = B * nx * D;

@@ -46,16 +46,30 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
   // ---- x, u of this knot (from the accepted candidate when there is one) ----
   double x[NX], u[NU];
   {
-    const double *src = acc >= 0 ? a.xs_try + ((size_t)acc * TB1 + tb) * NX : a.xs + tb * NX;
-    ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = src[i];
+    if (acc >= 0 && ASLR_CAND_INTERLEAVED(NX)) {
+      ASLR_UNROLL for (int p = 0; p < NX / 2; ++p) {
+        const double2 v = *reinterpret_cast<const double2 *>(a.xs_try + cand_piece<NX>(acc, t, b, p, B, T + 1));
+        x[2 * p] = v.x; x[2 * p + 1] = v.y;
+      }
+    } else {
+      const double *src = acc >= 0 ? a.xs_try + ((size_t)acc * TB1 + tb) * NX : a.xs + tb * NX;
+      ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = src[i];
+    }
     if (acc >= 0 && valid) {
       double *dst = a.xs + tb * NX;
       ASLR_UNROLL for (int i = 0; i < NX; ++i) dst[i] = x[i];
     }
   }
   if (t < T) {
-    const double *src = acc >= 0 ? a.us_try + ((size_t)acc * TB + tb) * NU : a.us + tb * NU;
-    ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = src[i];
+    if (acc >= 0 && ASLR_CAND_INTERLEAVED(NU)) {
+      ASLR_UNROLL for (int p = 0; p < NU / 2; ++p) {
+        const double2 v = *reinterpret_cast<const double2 *>(a.us_try + cand_piece<NU>(acc, t, b, p, B, T));
+        u[2 * p] = v.x; u[2 * p + 1] = v.y;
+      }
+    } else {
+      const double *src = acc >= 0 ? a.us_try + ((size_t)acc * TB + tb) * NU : a.us + tb * NU;
+      ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = src[i];
+    }
     if (acc >= 0 && valid) {
       double *dst = a.us + tb * NU;
       ASLR_UNROLL for (int i = 0; i < NU; ++i) dst[i] = u[i];
@@ -90,10 +104,19 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
       double mx = 0.0;
       if (t < T) {
         const size_t tb1 = tb + B;
-        const double *src = acc >= 0 ? a.xs_try + ((size_t)acc * TB1 + tb1) * NX : a.xs + tb1 * NX;
+        double nxt[NX]; // the state the next knot starts from
+        if (acc >= 0 && ASLR_CAND_INTERLEAVED(NX)) {
+          ASLR_UNROLL for (int p = 0; p < NX / 2; ++p) {
+            const double2 v = *reinterpret_cast<const double2 *>(a.xs_try + cand_piece<NX>(acc, t + 1, b, p, B, T + 1));
+            nxt[2 * p] = v.x; nxt[2 * p + 1] = v.y;
+          }
+        } else {
+          const double *src = acc >= 0 ? a.xs_try + ((size_t)acc * TB1 + tb1) * NX : a.xs + tb1 * NX;
+          ASLR_UNROLL for (int i = 0; i < NX; ++i) nxt[i] = src[i];
+        }
         double *g = a.gaps + tb1 * NX;
         ASLR_UNROLL for (int i = 0; i < NX; ++i) {
-          const double f = xnext[i] - src[i];
+          const double f = xnext[i] - nxt[i];
           g[i] = f;
           mx = fmax(mx, fabs(f));
         }

@@ -41,6 +41,15 @@ struct KArgs {
   int32_t planar; // the chain qualifies for the planar dynamics path (DevDesc::planar.ok)
 };
 
+// Line-search candidates (XS_TRY / US_TRY, layout in include/aslr_to_amd.h): 16-byte piece p of trajectory b at knot t of
+// step length ai; W = doubles per candidate, TK = knots stored (T + 1 or T)
+template <int W>
+ASLR_DEV size_t cand_piece(int ai, int t, int b, int p, int B, int TK) {
+  const size_t slab = (size_t)ASLR_CAND_SLAB(B, W);
+  const size_t in_slab = ASLR_CAND_INTERLEAVED(W) ? ((size_t)(b >> 2) * (W / 2) + p) * 8 + (size_t)(b & 3) * 2 : (size_t)b * W + 2 * p;
+  return ((size_t)ai * TK + t) * slab + in_slab;
+}
+
 // node -> action-model index, read through the constant address space: the table is never written by a kernel, and a
 // scalar load keeps it out of vmcnt (as a vector load its wait drained every prefetch issued just before it)
 ASLR_DEV int node_model_at(const KArgs &a, int t) {

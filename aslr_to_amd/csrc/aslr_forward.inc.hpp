@@ -40,7 +40,6 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
   const bool use_gaps = fddp && !(feasible || alpha == 1.0);
   const bool need_dv = fddp && !feasible;
   const DevDesc &D = *a.desc;
-  const size_t TB1 = (size_t)(T + 1) * B, TB = (size_t)T * B;
 
   double x[NX], dv = 0.0;
   bool fail = false;
@@ -85,7 +84,6 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
   };
   prefetch(0);
   for (int t = 0; t <= T; ++t) {
-    const size_t tb = (size_t)t * B + b;
     // inputs of knot t have landed (issued one knot ago, before that knot's NST candidate stores)
     if (t == 0) wait_vmcnt<0>(); else wait_vmcnt<NST>();
     wave_sync();
@@ -102,9 +100,9 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
       ASLR_UNROLL for (int i = 0; i < NX; ++i) s += S(oVf + i) * (S(oXr + i) - x[i]);
       dv -= s;
     }
-    if (lane_on) {
-      double *o = a.xs_try + ((size_t)ai * TB1 + tb) * NX;
-      ASLR_UNROLL for (int i = 0; i < NX; ++i) o[i] = x[i];
+    if (lane_on) { // (piece-interleaved slab: the 4 teams of the wave write neighbouring 16-byte pieces)
+      ASLR_UNROLL for (int p = 0; p < NX / 2; ++p)
+        *reinterpret_cast<double2 *>(a.xs_try + cand_piece<NX>(ai, t, b, p, B, T + 1)) = make_double2(x[2 * p], x[2 * p + 1]);
     }
     if (t == T) break;
     double u[NU];
@@ -118,8 +116,8 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
       ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = fmin(fmax(u[i], lim.lb[m_now][i]), lim.ub[m_now][i]);
     }
     if (lane_on) {
-      double *o = a.us_try + ((size_t)ai * TB + tb) * NU;
-      ASLR_UNROLL for (int i = 0; i < NU; ++i) o[i] = u[i];
+      ASLR_UNROLL for (int p = 0; p < NU / 2; ++p)
+        *reinterpret_cast<double2 *>(a.us_try + cand_piece<NU>(ai, t, b, p, B, T)) = make_double2(u[2 * p], u[2 * p + 1]);
     }
     const DevModel &dm = D.models[m_now];
     if (m_now != m_loaded) { mr.load(dm); m_loaded = m_now; } // wave-uniform
@@ -148,11 +146,24 @@ __global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
   if (!valid || done) return;
   const size_t TB1 = (size_t)(T + 1) * B, TB = (size_t)T * B, tb = (size_t)t * B + b;
   double x[NX], u[NU], xnext[NX], c = 0.0;
-  const double *xs = a.xs_try + ((size_t)ai * TB1 + tb) * NX;
-  ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = xs[i];
-  if (t < T) {
-    const double *us = a.us_try + ((size_t)ai * TB + tb) * NU;
-    ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = us[i];
+  if (NX % 2 == 0 && NU % 2 == 0) {
+    ASLR_UNROLL for (int p = 0; p < NX / 2; ++p) {
+      const double2 v = *reinterpret_cast<const double2 *>(a.xs_try + cand_piece<NX>(ai, t, b, p, B, T + 1));
+      x[2 * p] = v.x; x[2 * p + 1] = v.y;
+    }
+    if (t < T) {
+      ASLR_UNROLL for (int p = 0; p < NU / 2; ++p) {
+        const double2 v = *reinterpret_cast<const double2 *>(a.us_try + cand_piece<NU>(ai, t, b, p, B, T));
+        u[2 * p] = v.x; u[2 * p + 1] = v.y;
+      }
+    }
+  } else { // plain slabs (odd widths)
+    const double *xs = a.xs_try + ((size_t)ai * TB1 + tb) * NX;
+    ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = xs[i];
+    if (t < T) {
+      const double *us = a.us_try + ((size_t)ai * TB + tb) * NU;
+      ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = us[i];
+    }
   }
   const DevDesc &D = *a.desc;
   const DevModel &dm = D.models[node_model_at(a, t)];

@@ -76,6 +76,17 @@ class Engine(object):
             _abi.R_TRAJ_F: (_abi.TF_COUNT, B), _abi.R_X0: (B, nx), _abi.R_FRAME_REF: (B, 12),
             _abi.R_VXXF: (T + 1, B, nx), _abi.R_COST_TRY: (_abi.NALPHA, T + 1, B),
         }
+        if rid in (_abi.R_XS_TRY, _abi.R_US_TRY):
+            # candidate slabs: for even widths <= 8 piece-interleaved in groups of 4 trajectories
+            # ([ceil(B / 4)][w / 2][4][2], include/aslr_to_amd.h) -- returned as a de-interleaved COPY
+            # [NALPHA][knots][B][w] (not cached: it would go stale)
+            w, knots = (nx, T + 1) if rid == _abi.R_XS_TRY else (nu, T)
+            f = raw.view(torch.float64)
+            if w % 2 == 0 and w <= 8:
+                G = (B + 3) // 4
+                return (f.view(_abi.NALPHA, knots, G, w // 2, 4, 2).permute(0, 1, 2, 4, 3, 5)
+                        .reshape(_abi.NALPHA, knots, G * 4, w)[:, :, :B].contiguous())
+            return f.view(_abi.NALPHA, knots, B, w)
         if rid == _abi.R_TRAJ_I:
             v = raw.view(torch.int32).view(_abi.TI_COUNT, B)
         elif rid == _abi.R_NODE_MODEL:

@@ -174,8 +174,12 @@ typedef struct aslr_solver_params {
  *   QU      [T][B][nu]          solver.Qu
  *   VX      [T+1][B][nx]        solver.Vx
  *   VXX     [T+1][B][nx*nx]     solver.Vxx
- *   XS_TRY  [NALPHA][T+1][B][nx]  line-search candidates
- *   US_TRY  [NALPHA][T][B][nu]
+ *   XS_TRY  [NALPHA][T+1][slab]   line-search candidates; slab = the B candidates of one (alpha, knot):
+ *   US_TRY  [NALPHA][T][slab]       entries of width w = nx / nu doubles.  For even w <= 8 the slab is
+ *                                   PIECE-INTERLEAVED in groups of 4 trajectories: [ceil(B / 4)][w / 2][4][2], i.e. entry e of
+ *                                   trajectory b at ((b / 4) (w / 2) + e / 2) 8 + (b % 4) 2 + e % 2 (the four trajectories a wave
+ *                                   of the rollout handles store neighbouring 16-byte pieces); otherwise plain [B][w].
+ *                                   ASLR_CAND_SLAB / ASLR_CAND_OFFSET below.
  *   VXXF    [T+1][B][nx]        Vxx[t] fs[t] (FDDP expected improvement)
  *   COST_TRY [NALPHA][T+1][B]   node costs of every line-search candidate
  *   DYN     [T+1][B][2nj+3nj^2] rigid-body intermediates of calcDiff (xout, M^-1, dtau/dq, dtau/dv) handed from
@@ -191,6 +195,12 @@ enum aslr_region_id {
 };
 
 /* rows of TRAJ_F */
+/* candidate slabs (XS_TRY / US_TRY): doubles per (alpha, knot) and offset of entry e of trajectory b inside one */
+#define ASLR_CAND_INTERLEAVED(w) ((w) % 2 == 0 && (w) <= 8)
+#define ASLR_CAND_SLAB(B, w) (ASLR_CAND_INTERLEAVED(w) ? (((int64_t)(B) + 3) / 4) * 4 * (w) : (int64_t)(B) * (w))
+#define ASLR_CAND_OFFSET(b, e, w) \
+  (ASLR_CAND_INTERLEAVED(w) ? (((int64_t)(b) / 4) * ((w) / 2) + (e) / 2) * 8 + ((b) % 4) * 2 + (e) % 2 : (int64_t)(b) * (w) + (e))
+
 enum {
   ASLR_TF_COST = 0, ASLR_TF_STOP, ASLR_TF_XREG, ASLR_TF_D1, ASLR_TF_D2, ASLR_TF_STEP,
   ASLR_TF_DV, ASLR_TF_DVEXP, ASLR_TF_DG, ASLR_TF_DQ, ASLR_TF_COST_TRY0 /* ..+NALPHA */,
