@@ -13,7 +13,7 @@ MAX_NU = 14
 MAX_COSTS = 6
 MAX_MODELS = 4
 NALPHA = 10
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, E_INVALID, E_HIP, E_NODEVICE, E_WORKSPACE = 0, -1, -2, -3, -4
 DAM_SEA, DAM_VSA = 0, 1
@@ -32,6 +32,10 @@ TF_COUNT = TF_DVTRY0 + NALPHA
 (TI_ITER, TI_STATUS, TI_FEASIBLE, TI_WAS_FEASIBLE, TI_RECALC, TI_ACCEPTED, TI_DONE, TI_NTRIALS,
  TI_GAPFLAG, TI_TRYFAIL0) = range(10)
 TI_COUNT = TI_TRYFAIL0 + NALPHA
+
+# rows of the per-iteration log (aslr_set_iteration_log)
+(LOG_COST, LOG_STOP, LOG_XREG, LOG_STEP, LOG_D1, LOG_D2, LOG_DV, LOG_DVEXP, LOG_ACCEPTED, LOG_STATUS, LOG_FEASIBLE,
+ LOG_COUNT) = range(12)
 
 _d = C.c_double
 _i = C.c_int32
@@ -135,6 +139,7 @@ EXPORTED_SYMBOLS = [
     "aslr_workspace_bytes", "aslr_problem_create", "aslr_problem_destroy", "aslr_problem_region",
     "aslr_calc", "aslr_calc_diff", "aslr_backward_pass", "aslr_forward_pass", "aslr_solve",
     "aslr_iterate", "aslr_iterate_timed", "aslr_finalize", "aslr_count_active", "aslr_dam_eval", "aslr_quasi_static", "aslr_last_error",
+    "aslr_dam_residuals", "aslr_residual_len", "aslr_frame_placement", "aslr_set_iteration_log",
 ]
 
 
@@ -190,6 +195,14 @@ def load_library():
     lib.aslr_quasi_static.restype = C.c_int
     lib.aslr_quasi_static.argtypes = [vp, i32, C.c_double, vp, vp]
     lib.aslr_last_error.restype = C.c_char_p
+    lib.aslr_dam_residuals.restype = C.c_int
+    lib.aslr_dam_residuals.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    lib.aslr_residual_len.restype = i32
+    lib.aslr_residual_len.argtypes = [C.POINTER(Model), i32]
+    lib.aslr_frame_placement.restype = C.c_int
+    lib.aslr_frame_placement.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), i32, vp, i64, vp, vp]
+    lib.aslr_set_iteration_log.restype = C.c_int
+    lib.aslr_set_iteration_log.argtypes = [vp, vp, i32]
     if lib.aslr_abi_version() != ABI_VERSION:
         raise ImportError("aslr_to_amd: ABI version mismatch between %s and the Python layer" % path)
     for which, st in enumerate((Chain, Cost, Model, ProblemDesc, SolverParams, Region)):

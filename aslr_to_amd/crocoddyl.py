@@ -20,15 +20,72 @@ from .models import (ActivationModelQuad, ActivationModelWeightedQuad, CostModel
                      CostModelSum, Jcomponent, ResidualModelControl, ResidualModelState)
 
 
+class _NodePinocchio(object):
+    """data.differential.multibody.pinocchio of a node: oMf[frame_id] from the GPU (aslr_frame_placement at the
+    node's link positions XS[t]), what the scripts print after a solve (examples/two_dof_sea.py:82-86,
+    examples/two_dof_vsa_boxddp.py:83-84).  B = 1: an object with .rotation / .translation; a batch: the same with a
+    leading batch dimension (device tensors)."""
+
+    def __init__(self, node):
+        self._node = node
+
+    @property
+    def oMf(self):
+        return _NodeFrames(self._node)
+
+
+class _NodeFrames(object):
+    def __init__(self, node):
+        self._node = node
+
+    def __getitem__(self, fid):
+        from .engine import _SE3View
+        p, t = self._node._p, self._node._t
+        e = p.engine
+        model = p.runningModels[0].state.pinocchio if p.runningModels else p.terminalModel.state.pinocchio
+        fr = model.frames[fid]
+        if fr.parent < 0:
+            return _SE3View(fr.placement.rotation.copy(), fr.placement.translation.copy())
+        x = e.region(_abi.R_XS)[t]  # [B, nx], contiguous
+        R, pos = e.frame_placement(fr.parent, fr.placement.rotation, fr.placement.translation, x)
+        if p.batch == 1:
+            return _SE3View(R[0].cpu().numpy(), pos[0].cpu().numpy())
+        return _SE3View(R, pos)
+
+    def __len__(self):
+        p = self._node._p
+        model = p.runningModels[0].state.pinocchio if p.runningModels else p.terminalModel.state.pinocchio
+        return len(model.frames)
+
+
+class _NodeMultibody(object):
+    def __init__(self, node):
+        self.pinocchio = _NodePinocchio(node)
+
+
 class _NodeData(object):
-    """runningDatas[t] / terminalData: views of the engine's per-node results (B = 1)."""
+    """runningDatas[t] / terminalData: views of the engine's per-node results."""
 
     def __init__(self, problem, t):
         self._p, self._t = problem, t
         self.differential = self
+        self.multibody = _NodeMultibody(self)
+        self.pinocchio = self.multibody.pinocchio
 
     def _blk(self, name):
         return self._p.engine.deriv_block(name)[self._t, 0].cpu().numpy()
+
+    @property
+    def r(self):
+        """data.r: the stacked cost residuals of this node (integrated_action.py:17-18), trajectory 0."""
+        p, t = self._p, self._t
+        e = p.engine
+        model = p.runningModels[t] if t < p.T else p.terminalModel
+        x = e.region(_abi.R_XS)[t, 0].cpu().numpy()
+        u = e.region(_abi.R_US)[t, 0].cpu().numpy() if t < p.T else model.differential._default_u()
+        mi = int(p.lowered.node_model[t])
+        dam = model.differential
+        return dam.costs.order_residuals(e.dam_residuals(mi, x, u)[0], dam.state.ndx, dam.nu)
 
     xnext = property(lambda s: s._p.engine.region(_abi.R_XNEXT)[s._t, 0].cpu().numpy())
     cost = property(lambda s: float(s._p.engine.region(_abi.R_COST)[s._t, 0].item()))
@@ -110,14 +167,23 @@ class ShootingProblem(object):
         running the forward kernel with zero gains (K = 0, k = 0, alpha = 1)."""
         import torch
         e = self.engine
+        # the solver's state the forward kernel reads is saved and put back: rollout() has no side effect on a
+        # solve in progress (gains, candidate, feasibility flags)
+        rids = (_abi.R_XS, _abi.R_US, _abi.R_KGAIN, _abi.R_KFF)
+        keep = [(r, e.region(r).clone()) for r in rids]
+        feas = e.region(_abi.R_TRAJ_I)[_abi.TI_FEASIBLE].clone()
         e.set_candidate(None, us)
         e.region(_abi.R_KGAIN).zero_()
         e.region(_abi.R_KFF).zero_()
         e.region(_abi.R_TRAJ_I)[_abi.TI_FEASIBLE].fill_(1)
         e.forward_pass(_abi.default_solver_params(_abi.SOLVER_DDP))
         xs = e.region(_abi.R_XS_TRY)[0].permute(1, 0, 2)
+        out = [x for x in xs[0].cpu().numpy()] if self.batch == 1 else xs.clone()
+        for r, t in keep:
+            e.region(r).copy_(t)
+        e.region(_abi.R_TRAJ_I)[_abi.TI_FEASIBLE].copy_(feas)
         torch.cuda.synchronize(e.device)
-        return [x for x in xs[0].cpu().numpy()] if self.batch == 1 else xs.clone()
+        return out
 
     def quasiStatic(self, xs, maxiter=100, tol=1e-9):
         """us[t] holding xs[t] still under node t's model (examples/two_dof_sea.py:78); xs has T entries."""
@@ -145,36 +211,80 @@ class ShootingProblem(object):
 
 
 class CallbackLogger(object):
-    """Records per-iteration scalars and the final xs/us (examples/double_pendulum.py:77-79)."""
+    """crocoddyl.CallbackLogger (examples/double_pendulum.py:77-79, examples/two_dof_sea.py:75): per-iteration
+    `costs, u_regs, x_regs, grads, stops, steps, iters` and the solver's latest `xs, us, fs`.
+    B = 1: plain Python lists, one entry per iteration, as in Crocoddyl.  A batch: after solve() the same names hold
+    numpy arrays [iterations, B] (NaN where a trajectory had already stopped) and `iters` the per-trajectory
+    iteration counts; they come from the device-resident log in one transfer."""
 
     def __init__(self):
-        self.xs, self.us = [], []
+        self.xs, self.us, self.fs = [], [], []
         self.costs, self.u_regs, self.x_regs, self.grads, self.stops, self.steps = [], [], [], [], [], []
         self.iters = []
 
     def __call__(self, solver):
-        self.xs, self.us = solver.xs, solver.us
+        self.xs, self.us, self.fs = solver.xs, solver.us, solver.fs
         self.iters.append(solver.iter)
         self.costs.append(solver.cost)
         self.u_regs.append(solver.u_reg)
         self.x_regs.append(solver.x_reg)
-        self.grads.append(solver.d[0])
+        self.grads.append(-solver.d[1])   # Crocoddyl: -expectedImprovement()[1]
         self.stops.append(solver.stop)
         self.steps.append(solver.stepLength)
 
+    def from_batch_log(self, solver, log, iters):
+        """log: numpy [n, LOG_COUNT, B]; iters: per-trajectory iteration counts."""
+        self.xs, self.us, self.fs = solver.xs, solver.us, solver.fs
+        self.costs, self.stops = log[:, _abi.LOG_COST], log[:, _abi.LOG_STOP]
+        self.x_regs = self.u_regs = log[:, _abi.LOG_XREG]
+        self.grads, self.steps = -log[:, _abi.LOG_D2], log[:, _abi.LOG_STEP]
+        self.iters = iters
+
 
 class CallbackVerbose(object):
+    """crocoddyl.CallbackVerbose: one table row per iteration -- iter, cost, stop, grad (= -d[1]), xreg, ureg, step,
+    feas -- with the header repeated every 10 iterations (the layout of the Crocoddyl 1.x generation the reference
+    was written against; unverifiable here).  For a batch one row per lock-step iteration with the
+    active-trajectory count, the summed cost and the largest stop / regularisation of the active trajectories."""
+
     def __init__(self, out=None):
         self.out = out or sys.stdout
-        self._n = 0
 
     def __call__(self, solver):
-        if self._n % 10 == 0:
-            self.out.write("iter     cost         stop         grad         xreg         ureg       step    ||ffeas||\n")
-        self._n += 1
-        self.out.write("%4d  %0.5e  %0.5e  %0.5e  %0.5e  %0.5e  %0.4f  %d\n" % (
-            solver.iter, solver.cost, solver.stop, solver.d[0], solver.x_reg, solver.u_reg, solver.stepLength,
+        if solver.iter % 10 == 0:
+            self.out.write("iter \t cost \t      stop \t    grad \t  xreg \t      ureg \t step \t feas\n")
+        self.out.write("%4d  %.5e  %.5e  %.5e  %.5e  %.5e  %.4f     %d\n" % (
+            solver.iter, solver.cost, solver.stop, -solver.d[1], solver.x_reg, solver.u_reg, solver.stepLength,
             1 if solver.isFeasible else 0))
+
+    def from_batch_log(self, solver, log, iters):
+        for i in range(log.shape[0]):
+            on = ~np.isnan(log[i, _abi.LOG_COST])
+            if not on.any():
+                break
+            if i % 10 == 0:
+                self.out.write("iter  active   sum cost     max stop     max grad     max xreg   mean step\n")
+            self.out.write("%4d  %6d  %.5e  %.5e  %.5e  %.5e  %.4f\n" % (
+                i, int(on.sum()), log[i, _abi.LOG_COST][on].sum(), log[i, _abi.LOG_STOP][on].max(),
+                (-log[i, _abi.LOG_D2][on]).max(), log[i, _abi.LOG_XREG][on].max(), log[i, _abi.LOG_STEP][on].mean()))
+
+
+class _IterationView(object):
+    """The solver as a callback of iteration i saw it (B = 1), rebuilt from row i of the device log."""
+
+    def __init__(self, solver, row, i):
+        self._s = solver
+        self.iter = i
+        self.cost, self.stop = float(row[_abi.LOG_COST]), float(row[_abi.LOG_STOP])
+        self.x_reg = self.u_reg = float(row[_abi.LOG_XREG])
+        self.stepLength = float(row[_abi.LOG_STEP])
+        self.d = [float(row[_abi.LOG_D1]), float(row[_abi.LOG_D2])]
+        self.dV, self.dVexp = float(row[_abi.LOG_DV]), float(row[_abi.LOG_DVEXP])
+        self.isFeasible = int(row[_abi.LOG_FEASIBLE])
+        self.status = int(row[_abi.LOG_STATUS])
+
+    def __getattr__(self, name):  # xs, us, fs, problem, K ...: the solver's (final) ones
+        return getattr(self._s, name)
 
 
 class SolverDDP(object):
@@ -188,6 +298,7 @@ class SolverDDP(object):
         sp = _abi.default_solver_params(self._solver)
         self._sp = sp
         self._callbacks = []
+        self.keep_log = False   # record the per-iteration log even without callbacks (iteration_log())
         self.poll_every = 4
         self.batch_iters = 0
 
@@ -229,25 +340,60 @@ class SolverDDP(object):
         sp.is_feasible = 1 if isFeasible else 0
         sp.reg_init = float("nan") if regInit is None else float(regInit)
         e.set_candidate(init_xs, init_us)
-        if self._callbacks and self.problem.batch == 1:
-            # per-iteration callbacks need a host round trip per iteration
-            done_iters = sp.maxiter
-            for it in range(sp.maxiter):
-                e.iterate(sp, it == 0)
-                active = e.count_active()
-                for cb in self._callbacks:
-                    cb(self)
-                if active == 0 and not sp.fixed_iterations:
-                    done_iters = it + 1
-                    break
-            it = done_iters
-            e.finalize()
-            self.batch_iters = it
-        else:
-            self.batch_iters = e.solve(sp, self.poll_every)
+        # callbacks: the line-search kernel records what they read into a device-resident log; the solve runs
+        # without a host round trip per iteration and the callbacks are replayed from the log afterwards
+        e.enable_iteration_log(sp.maxiter if (self._callbacks or self.keep_log) and sp.maxiter > 0 else 0)
+        self.batch_iters = e.solve(sp, self.poll_every)
         torch.cuda.synchronize(e.device)
         st = e.traj_i(_abi.TI_STATUS)
+        if self._callbacks:
+            self._replay_callbacks()
         return bool(((st & _abi.ST_CONVERGED) != 0).all().item())
+
+    def iteration_log(self):
+        """numpy [iterations, LOG_COUNT, B] of the last solve (needs callbacks or `keep_log = True`), trimmed to the
+        iterations some trajectory ran; NaN where a trajectory had stopped.  Fields: _abi.LOG_*."""
+        lg = self.problem.engine.iteration_log()
+        if lg is None:
+            return None
+        n = int(self.problem.engine.traj_i(_abi.TI_ITER).max().item())
+        return lg[:min(n, lg.shape[0])].cpu().numpy()
+
+    def _replay_callbacks(self):
+        log = self.iteration_log()
+        iters = self.problem.engine.traj_i(_abi.TI_ITER).cpu().numpy()
+        if self._single():
+            for i in range(log.shape[0]):
+                row = log[i, :, 0]
+                # Crocoddyl returns from solve() before the callbacks when the regularisation hits its maximum
+                if int(row[_abi.LOG_STATUS]) & _abi.ST_REG_MAX:
+                    break
+                view = _IterationView(self, row, i)
+                for cb in self._callbacks:
+                    cb(view)
+        else:
+            for cb in self._callbacks:
+                if hasattr(cb, "from_batch_log"):
+                    cb.from_batch_log(self, log, iters)
+                else:
+                    raise TypeError("callback %r cannot consume a batch log (needs from_batch_log)" % (cb,))
+
+    def export_solution(self, path, trajectory=0):
+        """The arrays examples/two_dof_vsa_boxddp.py:104-127 saves to .mat files, as one .npz: t [T], q [T+1, nj]
+        (link positions), u [T, nj] (motor commands), stiffness [T, nj] (VSA models; empty otherwise), xs, us.
+        trajectory: index in the batch, or None for all ([B, ...])."""
+        e = self.problem.engine
+        X = self.xs if not self._single() else np.asarray(self.xs)[None]
+        U = self.us if not self._single() else np.asarray(self.us)[None]
+        X = X.cpu().numpy() if hasattr(X, "cpu") else np.asarray(X)
+        U = U.cpu().numpy() if hasattr(U, "cpu") else np.asarray(U)
+        nj = e.nx // 4
+        dt = float(self.problem.runningModels[0].dt)
+        sel = slice(None) if trajectory is None else int(trajectory)
+        vsa = e.nu == 2 * nj
+        np.savez(path, t=np.arange(self.problem.T) * dt, q=X[sel][..., :nj], u=U[sel][..., :nj],
+                 stiffness=U[sel][..., nj:] if vsa else np.zeros(U[sel].shape[:-1] + (0,)), xs=X[sel], us=U[sel])
+        return path
 
     # -- results --
     def _single(self):

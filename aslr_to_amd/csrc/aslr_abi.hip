@@ -374,6 +374,7 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   k.traj_f = (double *)reg(ASLR_R_TRAJ_F); k.traj_i = (int32_t *)reg(ASLR_R_TRAJ_I);
   k.B = desc->B; k.T = desc->T;
   k.planar = planar_ok;
+  k.iter_log = nullptr; k.log_cap = 0;
   *out = p;
   return ASLR_OK;
 }
@@ -508,6 +509,55 @@ int aslr_dam_eval(aslr_problem_t *p, int32_t model_index, int32_t n, const doubl
   if (p->nj == 7) return launch_dam_eval_nj7(p->k, p->dam, model_index, n, x, u, xout, cost, Fx, Fu, Lx, Lu, Lxx, Lxu, Luu, st);
   snprintf(g_err, sizeof g_err, "unsupported nj=%d", p->nj);
   return ASLR_E_INVALID;
+}
+
+int32_t aslr_residual_len(const aslr_model_t *m, int32_t nj) {
+  if (!m || nj <= 0 || nj > ASLR_MAX_NJ || m->ncosts < 0 || m->ncosts > ASLR_MAX_COSTS) return ASLR_E_INVALID;
+  int nr = 0;
+  for (int c = 0; c < m->ncosts; ++c) {
+    switch (m->costs[c].type) {
+    case ASLR_COST_FRAME_PLACEMENT: nr += 6; break;
+    case ASLR_COST_STATE: nr += 4 * nj; break;
+    case ASLR_COST_CONTROL: nr += m->nu; break;
+    case ASLR_COST_PENDULUM: nr += 6; break;
+    case ASLR_COST_STIFFNESS: nr += m->nu / 2; break;
+    default: return ASLR_E_INVALID;
+    }
+  }
+  return nr;
+}
+
+int aslr_dam_residuals(aslr_problem_t *p, int32_t model_index, int32_t n, const double *x, const double *u, double *r,
+                       void *stream) {
+  if (!p || n <= 0 || model_index < 0 || model_index >= p->desc.nmodels || !x || !u || !r) return ASLR_E_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nr = aslr_residual_len(&p->desc.models[model_index], p->nj);
+  if (nr <= 0) return nr < 0 ? nr : ASLR_OK;
+  if (p->nj == 2) return launch_dam_residuals_nj2(p->k, p->dam, model_index, n, x, u, r, nr, st);
+  if (p->nj == 7) return launch_dam_residuals_nj7(p->k, p->dam, model_index, n, x, u, r, nr, st);
+  snprintf(g_err, sizeof g_err, "unsupported nj=%d", p->nj);
+  return ASLR_E_INVALID;
+}
+
+int aslr_frame_placement(aslr_problem_t *p, int32_t frame_joint, const double *frame_R, const double *frame_p, int32_t n,
+                         const double *x, int64_t x_stride, double *oMf, void *stream) {
+  if (!p || n <= 0 || frame_joint < 0 || frame_joint >= p->nj || !frame_R || !frame_p || !x || !oMf || x_stride < p->nj)
+    return ASLR_E_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  FrameArg F;
+  for (int i = 0; i < 9; ++i) F.R[i] = frame_R[i];
+  for (int i = 0; i < 3; ++i) F.p[i] = frame_p[i];
+  if (p->nj == 2) return launch_frame_placement_nj2(p->k, frame_joint, F, n, x, x_stride, oMf, st);
+  if (p->nj == 7) return launch_frame_placement_nj7(p->k, frame_joint, F, n, x, x_stride, oMf, st);
+  snprintf(g_err, sizeof g_err, "unsupported nj=%d", p->nj);
+  return ASLR_E_INVALID;
+}
+
+int aslr_set_iteration_log(aslr_problem_t *p, double *log, int32_t capacity) {
+  if (!p || (log && capacity <= 0)) return ASLR_E_INVALID;
+  p->k.iter_log = log;
+  p->k.log_cap = log ? capacity : 0;
+  return ASLR_OK;
 }
 
 int aslr_quasi_static(aslr_problem_t *p, int32_t maxiter, double tol, int32_t *iters_dev, void *stream) {

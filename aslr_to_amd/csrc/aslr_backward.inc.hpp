@@ -578,9 +578,14 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
         }
       }
       chk += fabs(Vx_own);
-      // NaN / Inf / >= 1e30 anywhere in Vx, Vxx -> "backward_error" (the 1-norm of the column stands in
-      // for Crocoddyl's inf-norm test; they differ only for entries within 8x of 1e30)
-      if (__ballot(is_bad(chk)) & team_mask) failed = true;
+      // NaN / Inf / >= 1e30 anywhere in Vx, Vxx -> "backward_error" (Crocoddyl's inf-norm test: the 1-norm of the
+      // column clears the common case, the entries decide otherwise)
+      {
+        double ent[NX + 1];
+        ASLR_UNROLL for (int r = 0; r < NX; ++r) ent[r] = Pcol[r];
+        ent[NX] = Vx_own;
+        if (__ballot(inf_norm_bad<NX + 1>(chk, ent)) & team_mask) failed = true;
+      }
       if (sp.store_v && st_ok && !failed) {
         a.vx[tb * NX + jj] = Vx_own;
         double *o = a.vxx + tb * NX * NX;

@@ -444,7 +444,8 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
         if (cell[h]) {
           double2 *po = reinterpret_cast<double2 *>(PT + rw * NX + 4 * g);
           po[0] = pa[h]; po[1] = pb[h];
-          bad = bad || is_bad(fabs(pa[h].x) + fabs(pa[h].y) + fabs(pb[h].x) + fabs(pb[h].y));
+          const double ent[4] = {pa[h].x, pa[h].y, pb[h].x, pb[h].y};
+          bad = bad || inf_norm_bad<4>(fabs(pa[h].x) + fabs(pa[h].y) + fabs(pb[h].x) + fabs(pb[h].y), ent);
         }
       }
       if (gaps_on) {

@@ -310,5 +310,63 @@ __global__ void __launch_bounds__(64) dam_eval_kernel(const DevDesc *desc, int m
   }
 }
 
+// aslr_dam_residuals: the stacked cost residuals (data.r) of arbitrary points, one lane per point
+template <int NJ, int DAM, bool PLANAR>
+__global__ void __launch_bounds__(64) dam_residual_kernel(const DevDesc *desc, int mi, const double *frame_ref, int n,
+                                                          const double *xin, const double *uin, double *r, int nr) {
+  constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n) return;
+  const DevDesc &D = *desc;
+  const DevModel &dm = D.models[mi];
+  double x[NX], u[NU], xnext[NX], c;
+  ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = xin[(size_t)p * NX + i];
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = uin[(size_t)p * NU + i];
+  using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
+  const typename CH::Consts cc(D);
+  ModelRegs<NJ, NU> mr;
+  mr.load(dm);
+  knot_eval<NJ, DAM, kEvalCost | kEvalResid, CH>(cc, mr, dm, frame_ref, x, u, xnext, c, nullptr, nullptr, nullptr,
+                                                 r + (size_t)p * nr);
+}
+
+// aslr_frame_placement: oMf = oMi[fj] * F at the link positions of n points (data.pinocchio.oMf of the scripts)
+template <int NJ, bool PLANAR>
+__global__ void __launch_bounds__(64) frame_placement_kernel(const DevDesc *desc, int fj, FrameArg F, int n,
+                                                             const double *xin, long long stride, double *out) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n) return;
+  using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
+  const typename CH::Consts cc(*desc);
+  double q[NJ];
+  ASLR_UNROLL for (int i = 0; i < NJ; ++i) q[i] = xin[(size_t)p * stride + i];
+  const SE3d oMj = CH::world_of(cc, q, fj);
+  SE3d Fl;
+  ASLR_UNROLL for (int i = 0; i < 9; ++i) Fl.R.a[i] = F.R[i];
+  Fl.p = V3{F.p[0], F.p[1], F.p[2]};
+  const SE3d oMf = se3_mul(oMj, Fl);
+  double *o = out + (size_t)p * 12;
+  ASLR_UNROLL for (int i = 0; i < 9; ++i) o[i] = oMf.R.a[i];
+  o[9] = oMf.p.x; o[10] = oMf.p.y; o[11] = oMf.p.z;
+}
+
+template <int NJ>
+int launch_frame_placement_t(const KArgs &k, int fj, const FrameArg &F, int n, const double *x, int64_t stride, double *out,
+                             hipStream_t st) {
+  dim3 grid((n + 63) / 64), block(64);
+  if (k.planar) hipLaunchKernelGGL((frame_placement_kernel<NJ, true>), grid, block, 0, st, k.desc, fj, F, n, x, (long long)stride, out);
+  else hipLaunchKernelGGL((frame_placement_kernel<NJ, false>), grid, block, 0, st, k.desc, fj, F, n, x, (long long)stride, out);
+  HIP_TRY(hipGetLastError());
+  return ASLR_OK;
+}
+
+template <int NJ, int DAM>
+int launch_dam_residuals_t(const KArgs &k, int mi, int n, const double *x, const double *u, double *r, int nr, hipStream_t st) {
+  dim3 grid((n + 63) / 64), block(64);
+  if (k.planar) hipLaunchKernelGGL((dam_residual_kernel<NJ, DAM, true>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, r, nr);
+  else hipLaunchKernelGGL((dam_residual_kernel<NJ, DAM, false>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, r, nr);
+  HIP_TRY(hipGetLastError());
+  return ASLR_OK;
+}
 
 } // namespace aslr

@@ -51,6 +51,17 @@ int launch_dam_eval_nj2(const KArgs &k, int dam, int mi, int n, const double *x,
   return ASLR_E_INVALID;
 }
 
+int launch_dam_residuals_nj2(const KArgs &k, int dam, int mi, int n, const double *x, const double *u, double *r, int nr, hipStream_t st) {
+  if (dam == ASLR_DAM_SEA) return launch_dam_residuals_t<2, ASLR_DAM_SEA>(k, mi, n, x, u, r, nr, st);
+  if (dam == ASLR_DAM_VSA) return launch_dam_residuals_t<2, ASLR_DAM_VSA>(k, mi, n, x, u, r, nr, st);
+  snprintf(err_buf(), kErrLen, "dam_residuals: unsupported (nj=2, dam=%d)", dam);
+  return ASLR_E_INVALID;
+}
+
+int launch_frame_placement_nj2(const KArgs &k, int fj, const FrameArg &F, int n, const double *x, int64_t stride, double *out, hipStream_t st) {
+  return launch_frame_placement_t<2>(k, fj, F, n, x, stride, out, st);
+}
+
 int launch_quasi_static_nj2(const KArgs &k, int dam, int maxiter, double tol, int32_t *iters, hipStream_t st) {
   dim3 grid((k.B + 63) / 64, k.T), block(64);
   if (dam == ASLR_DAM_SEA) {

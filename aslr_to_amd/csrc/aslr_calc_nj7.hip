@@ -36,6 +36,24 @@ int launch_dam_eval_nj7(const KArgs &k, int dam, int mi, int n, const double *x,
   return ASLR_E_INVALID;
 }
 
+int launch_dam_residuals_nj7(const KArgs &k, int dam, int mi, int n, const double *x, const double *u, double *r, int nr, hipStream_t st) {
+  dim3 grid((n + 63) / 64), block(64);
+  if (dam == ASLR_DAM_SEA) {
+    hipLaunchKernelGGL((dam_residual_kernel<7, ASLR_DAM_SEA, false>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, r, nr);
+    HIP_TRY(hipGetLastError());
+    return ASLR_OK;
+  }
+  snprintf(err_buf(), kErrLen, "dam_residuals: unsupported (nj=7, dam=%d)", dam);
+  return ASLR_E_INVALID;
+}
+
+int launch_frame_placement_nj7(const KArgs &k, int fj, const FrameArg &F, int n, const double *x, int64_t stride, double *out, hipStream_t st) {
+  dim3 grid((n + 63) / 64), block(64);
+  hipLaunchKernelGGL((frame_placement_kernel<7, false>), grid, block, 0, st, k.desc, fj, F, n, x, (long long)stride, out);
+  HIP_TRY(hipGetLastError());
+  return ASLR_OK;
+}
+
 int launch_quasi_static_nj7(const KArgs &k, int dam, int maxiter, double tol, int32_t *iters, hipStream_t st) {
   dim3 grid((k.B + 63) / 64, k.T), block(64);
   if (dam == ASLR_DAM_SEA) {

@@ -39,6 +39,8 @@ struct KArgs {
   int32_t *traj_i;
   int32_t B, T;
   int32_t planar; // the chain qualifies for the planar dynamics path (DevDesc::planar.ok)
+  double *iter_log;  // per-iteration log [log_cap][ASLR_LOG_COUNT][B] (aslr_set_iteration_log), or nullptr
+  int32_t log_cap;
 };
 
 // Line-search candidates (XS_TRY / US_TRY, layout in include/aslr_to_amd.h): 16-byte piece p of trajectory b at knot t of
@@ -75,6 +77,16 @@ struct ModelLimits {
 };
 
 __device__ __forceinline__ bool is_bad(double v) { return isnan(v) || isinf(v) || v >= 1e30; }
+// Crocoddyl's raiseIfNaN(v.lpNorm<Infinity>()) on a short vector: `s1` is the 1-norm of the same entries, which the
+// kernels accumulate anyway.  s1 < 1e30 proves every entry finite and below 1e30 (the common case: one compare);
+// otherwise (NaN, Inf, or a 1-norm that crossed 1e30 while the inf-norm may not have) the entries decide one by one.
+template <int N>
+__device__ __forceinline__ bool inf_norm_bad(double s1, const double (&v)[N]) {
+  if (__ballot(!(s1 < 1e30)) == 0ull) return false; // (wave-uniform: a real branch around the rare path)
+  bool bad = false;
+  _Pragma("unroll") for (int i = 0; i < N; ++i) bad = bad || is_bad(fabs(v[i]));
+  return bad;
+}
 
 // calc_kernel mode bits
 constexpr int kModeCommit = 1;    // copy the accepted candidate XS_TRY/US_TRY[acc] into XS/US
@@ -91,6 +103,11 @@ int launch_dam_eval_nj2(const KArgs &k, int dam, int mi, int n, const double *x,
 int launch_dam_eval_nj7(const KArgs &k, int dam, int mi, int n, const double *x, const double *u, double *xout,
                         double *cost, double *Fx, double *Fu, double *Lx, double *Lu, double *Lxx, double *Lxu,
                         double *Luu, hipStream_t st);
+int launch_dam_residuals_nj2(const KArgs &k, int dam, int mi, int n, const double *x, const double *u, double *r, int nr, hipStream_t st);
+int launch_dam_residuals_nj7(const KArgs &k, int dam, int mi, int n, const double *x, const double *u, double *r, int nr, hipStream_t st);
+struct FrameArg { double R[9], p[3]; }; // local placement of a frame on its joint, by value
+int launch_frame_placement_nj2(const KArgs &k, int fj, const FrameArg &F, int n, const double *x, int64_t stride, double *out, hipStream_t st);
+int launch_frame_placement_nj7(const KArgs &k, int fj, const FrameArg &F, int n, const double *x, int64_t stride, double *out, hipStream_t st);
 int launch_quasi_static_nj2(const KArgs &k, int dam, int maxiter, double tol, int32_t *iters, hipStream_t st);
 int launch_quasi_static_nj7(const KArgs &k, int dam, int maxiter, double tol, int32_t *iters, hipStream_t st);
 int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st);

@@ -1013,6 +1013,7 @@ constexpr int kEvalDiff = 4; // compact derivatives (implies both of the above)
 constexpr int kEvalPre = 8;  // the rigid-body part (xout, M^-1, dtau/dq, dtau/dv) is read from `pre` (DYN region)
 constexpr int kEvalSkipCost = 16; // with kEvalDiff: dynamics and its derivatives only (first half of a split evaluation)
 constexpr int kEvalSkipDyn = 32;  // with kEvalDiff: cost stack and its derivatives only (second half)
+constexpr int kEvalResid = 64;    // also store the stacked cost residuals (data.r) through `resid`
 
 // calc (+ calcDiff): x[4NJ], u[NU] -> xnext, cost (+ compact derivatives).
 // u == nullptr selects the model's "u is None" default (terminal node).
@@ -1022,8 +1023,10 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
                         const DevModel &dm, const double *frame_ref,
                         const double (&x)[4 * NJ], const double *u_in, double (&xnext)[4 * NJ],
                         double &cost_out, KnotDiff<NJ, ModelDims<NJ, DAM>::nu> *kd,
-                        double *xout_o = nullptr, const double *pre = nullptr) {
+                        double *xout_o = nullptr, const double *pre = nullptr, double *resid = nullptr) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
+  constexpr bool RESID = (WHAT & kEvalResid) != 0;
+  int roff = 0; // running offset into `resid`
   constexpr bool DIFF = (WHAT & kEvalDiff) != 0;
   constexpr bool DYN = (DIFF || (WHAT & kEvalDyn) != 0) && (WHAT & kEvalSkipDyn) == 0;
   constexpr bool COST = (DIFF || (WHAT & kEvalCost) != 0) && (WHAT & kEvalSkipCost) == 0;
@@ -1167,6 +1170,7 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
       double a = 0.0;
       ASLR_UNROLL for (int i = 0; i < 6; ++i) a += ct.act_w[i] * r[i] * r[i];
       cost += w * 0.5 * a;
+      if constexpr (RESID) { ASLR_UNROLL for (int i = 0; i < 6; ++i) resid[roff + i] = r[i]; roff += 6; }
       if (DIFF) {
         M3 A, Bm;
         jlog6_shared(rMf, lg, A, Bm);
@@ -1196,7 +1200,9 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
         const double r = x[i] - ct.ref[i];
         a += ct.act_w[i] * r * r;
         if (DIFF) { kd->Lx[i] += w * ct.act_w[i] * r; kd->Lxxd[i] += w * ct.act_w[i]; }
+        if constexpr (RESID) resid[roff + i] = r;
       }
+      if constexpr (RESID) roff += NX;
       cost += w * 0.5 * a;
     } else if (ct.type == ASLR_COST_CONTROL) {
       double a = 0.0;
@@ -1204,7 +1210,9 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
         const double r = u[i] - ct.ref[i];
         a += ct.act_w[i] * r * r;
         if (DIFF) { kd->Lu[i] += w * ct.act_w[i] * r; kd->Luud[i] += w * ct.act_w[i]; }
+        if constexpr (RESID) resid[roff + i] = r;
       }
+      if constexpr (RESID) roff += NU;
       cost += w * 0.5 * a;
     } else if (ct.type == ASLR_COST_PENDULUM) {
       if (NJ >= 2) {
@@ -1216,6 +1224,7 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
         double a = 0.0;
         ASLR_UNROLL for (int i = 0; i < 6; ++i) a += aw[i] * r[i] * r[i];
         cost += w * 0.5 * a;
+        if constexpr (RESID) { ASLR_UNROLL for (int i = 0; i < 6; ++i) resid[roff + i] = r[i]; roff += 6; }
         if (DIFF) {
           kd->Lx[0] += w * (c1 * aw[0] * r[0] - s1 * aw[2] * r[2]);
           kd->Lx[NJ >= 2 ? 1 : 0] += w * (c2 * aw[1] * r[1] - s2 * aw[3] * r[3]);
@@ -1233,7 +1242,9 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
       ASLR_UNROLL for (int i = 0; i < H; ++i) {
         a += ct.lambda * (u[H + i] - ct.ref[i]);
         if (DIFF) kd->Lu[H + i] += w * ct.lambda;
+        if constexpr (RESID) resid[roff + i] = ct.lambda * (u[H + i] - ct.ref[i]);
       }
+      if constexpr (RESID) roff += H;
       cost += w * a;
     }
   }

@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
     knot_eval<NJ, DAM, kEvalDyn, CH>(cc, mr, dm, nullptr, x, u, xnext, c, nullptr);
     double mx = 0.0;
     ASLR_UNROLL for (int i = 0; i < NX; ++i) { mx += fabs(xnext[i]); x[i] = xnext[i]; }
-    if (is_bad(mx)) fail = true; // NaN / Inf / >= 1e30 in the state ("forward_error")
+    if (inf_norm_bad<NX>(mx, xnext)) fail = true; // NaN / Inf / |xnext|_inf >= 1e30 ("forward_error")
   }
   if (lane_on) {
     TI[(ASLR_TI_TRYFAIL0 + ai) * B + b] = fail ? 1 : 0;
@@ -263,7 +263,22 @@ __global__ void __launch_bounds__(64) select_kernel(KArgs a, SolverDev sp) {
   }
   const double stop = TF[ASLR_TF_STOP * B + b];
   if (!fin && !sp.fixed_iterations && was_feasible && stop < sp.th_stop) { status |= ASLR_ST_CONVERGED; fin = 1; }
-  TI[ASLR_TI_ITER * B + b] += 1;
+  const int it = TI[ASLR_TI_ITER * B + b];
+  TI[ASLR_TI_ITER * B + b] = it + 1;
+  if (a.iter_log && it < a.log_cap) { // what the callbacks of this iteration would read (aslr_set_iteration_log)
+    double *lg = a.iter_log + (size_t)it * ASLR_LOG_COUNT * B + b;
+    lg[(size_t)ASLR_LOG_COST * B] = cost_acc;
+    lg[(size_t)ASLR_LOG_STOP * B] = stop;
+    lg[(size_t)ASLR_LOG_XREG * B] = xreg;
+    lg[(size_t)ASLR_LOG_STEP * B] = step;
+    lg[(size_t)ASLR_LOG_D1 * B] = d1;
+    lg[(size_t)ASLR_LOG_D2 * B] = d2;
+    lg[(size_t)ASLR_LOG_DV * B] = dV;
+    lg[(size_t)ASLR_LOG_DVEXP * B] = dVexp;
+    lg[(size_t)ASLR_LOG_ACCEPTED * B] = (double)accepted;
+    lg[(size_t)ASLR_LOG_STATUS * B] = (double)status;
+    lg[(size_t)ASLR_LOG_FEASIBLE * B] = (double)feas;
+  }
   TI[ASLR_TI_NTRIALS * B + b] += (accepted >= 0 ? accepted + 1 : ASLR_NALPHA);
   TI[ASLR_TI_STATUS * B + b] = status;
   TI[ASLR_TI_FEASIBLE * B + b] = feas;

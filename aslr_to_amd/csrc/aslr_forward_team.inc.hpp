@@ -270,7 +270,8 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
       const double ql = xT[cj], qm = xT[NJ + cj], vl = xT[2 * NJ + cj], vm = xT[3 * NJ + cj];
       const double nql = ql + (vl * dt + al * dt * dt), nvl = vl + al * dt;
       const double nqm = qm + (vm * dt + am * dt * dt), nvm = vm + am * dt;
-      const bool bad = jl && is_bad(fabs(nql) + fabs(nvl) + fabs(nqm) + fabs(nvm));
+      const double nxt[4] = {nql, nvl, nqm, nvm}; // this lane's entries of xnext: |xnext|_inf test, entry by entry
+      const bool bad = jl && inf_norm_bad<4>(fabs(nql) + fabs(nvl) + fabs(nqm) + fabs(nvm), nxt);
       if (__ballot(bad) & team_bits) fail = true; // NaN / Inf / >= 1e30 in the state ("forward_error")
       wave_sync(); // every lane of the team has read the old state
       if (jl) { xT[c] = nql; xT[NJ + c] = nqm; xT[2 * NJ + c] = nvl; xT[3 * NJ + c] = nvm; }

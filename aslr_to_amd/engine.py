@@ -47,6 +47,13 @@ class Engine(object):
         torch = _torch()
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _call(self, name, *args):
+        """One C-ABI call with this engine's device current (the ABI launches on the thread's current device, on a
+        stream that belongs to self.device): an Engine on cuda:1 works whatever the caller's current device is."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            _abi.check(getattr(self.lib, name)(self.handle, *args), name)
+
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle.value:
             self.lib.aslr_problem_destroy(self.handle)
@@ -145,47 +152,95 @@ class Engine(object):
 
     # ---- the hot path ----
     def calc(self):
-        _abi.check(self.lib.aslr_calc(self.handle, self._stream()), "aslr_calc")
+        self._call("aslr_calc", self._stream())
 
     def calc_diff(self):
-        _abi.check(self.lib.aslr_calc_diff(self.handle, self._stream()), "aslr_calc_diff")
+        self._call("aslr_calc_diff", self._stream())
 
     def backward_pass(self, sp):
-        _abi.check(self.lib.aslr_backward_pass(self.handle, C.byref(sp), self._stream()), "aslr_backward_pass")
+        self._call("aslr_backward_pass", C.byref(sp), self._stream())
 
     def forward_pass(self, sp):
-        _abi.check(self.lib.aslr_forward_pass(self.handle, C.byref(sp), self._stream()), "aslr_forward_pass")
+        self._call("aslr_forward_pass", C.byref(sp), self._stream())
 
     def iterate(self, sp, first):
-        _abi.check(self.lib.aslr_iterate(self.handle, C.byref(sp), 1 if first else 0, self._stream()), "aslr_iterate")
+        self._call("aslr_iterate", C.byref(sp), 1 if first else 0, self._stream())
 
     def iterate_timed(self, sp, first=False):
         """-> (calc_ms, backward_ms, forward_ms) of one iteration, from HIP events on the launch stream."""
         ms = (C.c_float * 3)()
-        _abi.check(self.lib.aslr_iterate_timed(self.handle, C.byref(sp), 1 if first else 0, self._stream(), ms),
-                   "aslr_iterate_timed")
+        self._call("aslr_iterate_timed", C.byref(sp), 1 if first else 0, self._stream(), ms)
         return tuple(float(v) for v in ms)
 
     def quasi_static(self, maxiter=100, tol=1e-9):
         """Fill US with the quasi-static controls of the states in XS; returns the [T, B] iteration counts."""
         torch = _torch()
         iters = torch.zeros((self.T, self.B), dtype=torch.int32, device=self.device)
-        _abi.check(self.lib.aslr_quasi_static(self.handle, int(maxiter), float(tol), C.c_void_p(iters.data_ptr()),
-                                              self._stream()), "aslr_quasi_static")
+        self._call("aslr_quasi_static", int(maxiter), float(tol), C.c_void_p(iters.data_ptr()), self._stream())
         return iters
 
     def finalize(self):
-        _abi.check(self.lib.aslr_finalize(self.handle, self._stream()), "aslr_finalize")
+        self._call("aslr_finalize", self._stream())
 
     def count_active(self):
         n = C.c_int32(0)
-        _abi.check(self.lib.aslr_count_active(self.handle, self._stream(), C.byref(n)), "aslr_count_active")
+        self._call("aslr_count_active", self._stream(), C.byref(n))
         return n.value
 
     def solve(self, sp, poll_every=4):
         it = C.c_int32(0)
-        _abi.check(self.lib.aslr_solve(self.handle, C.byref(sp), poll_every, self._stream(), C.byref(it)), "aslr_solve")
+        self._call("aslr_solve", C.byref(sp), poll_every, self._stream(), C.byref(it))
         return it.value
+
+    # ---- per-iteration log, frame placements, residuals ----
+    def enable_iteration_log(self, capacity):
+        """Device-resident log of the per-iteration solver state ([capacity, LOG_COUNT, B], NaN = not written): the
+        line-search kernel fills it, nothing crosses PCIe until `iteration_log()` is read.  capacity 0 / None: off."""
+        torch = _torch()
+        if not capacity:
+            self._log = None
+            self._call("aslr_set_iteration_log", C.c_void_p(0), 0)
+            return None
+        with torch.cuda.device(self.device):
+            self._log = torch.full((int(capacity), _abi.LOG_COUNT, self.B), float("nan"), dtype=torch.float64,
+                                   device=self.device)
+        self._call("aslr_set_iteration_log", C.c_void_p(self._log.data_ptr()), int(capacity))
+        return self._log
+
+    def iteration_log(self):
+        """The log tensor ([capacity, LOG_COUNT, B], on the device), or None when logging is off."""
+        return getattr(self, "_log", None)
+
+    def frame_placement(self, frame_joint, frame_R, frame_p, x, x_stride=None):
+        """World placements of a frame (joint index + local placement) at the link positions of `x`
+        (a device tensor [..., >= nj], contiguous): -> ([..., 3, 3], [..., 3]) device tensors."""
+        torch = _torch()
+        x = x.contiguous()
+        stride = x.shape[-1] if x_stride is None else int(x_stride)
+        n = x.numel() // x.shape[-1]
+        out = torch.empty((n, 12), dtype=torch.float64, device=self.device)
+        R = (C.c_double * 9)(*[float(v) for v in np.asarray(frame_R, dtype=np.float64).reshape(9)])
+        pv = (C.c_double * 3)(*[float(v) for v in np.asarray(frame_p, dtype=np.float64).reshape(3)])
+        self._call("aslr_frame_placement", int(frame_joint), R, pv, n, C.c_void_p(x.data_ptr()), stride,
+                   C.c_void_p(out.data_ptr()), self._stream())
+        lead = tuple(x.shape[:-1])
+        return out[:, :9].reshape(lead + (3, 3)), out[:, 9:].reshape(lead + (3,))
+
+    def dam_residuals(self, model_index, x, u):
+        """Stacked cost residuals (data.r) of n points, in the order of the model's cost list: numpy [n, nr]."""
+        torch = _torch()
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        u = np.atleast_2d(np.asarray(u, dtype=np.float64))
+        nr = self.lib.aslr_residual_len(C.byref(self.low.desc.models[model_index]), self.nx // 4)
+        if nr < 0:
+            raise _abi.AslrError("aslr_residual_len failed")
+        dx = torch.as_tensor(x, device=self.device).contiguous()
+        du = torch.as_tensor(u, device=self.device).contiguous()
+        r = torch.zeros((x.shape[0], max(nr, 1)), dtype=torch.float64, device=self.device)
+        if nr > 0:
+            self._call("aslr_dam_residuals", model_index, x.shape[0], C.c_void_p(dx.data_ptr()),
+                       C.c_void_p(du.data_ptr()), C.c_void_p(r.data_ptr()), self._stream())
+        return r[:, :nr].cpu().numpy()
 
     def traj_f(self, row):
         return self.region(_abi.R_TRAJ_F)[row]
@@ -205,10 +260,8 @@ class Engine(object):
                 "Lxx": (n, nx, nx), "Lxu": (n, nx, nu), "Luu": (n, nu, nu)}
         t = {k: torch.empty(s, dtype=torch.float64, device=self.device) for k, s in outs.items()}
         p = lambda k: C.c_void_p(t[k].data_ptr())
-        _abi.check(self.lib.aslr_dam_eval(self.handle, model_index, n, C.c_void_p(dx.data_ptr()),
-                                          C.c_void_p(du.data_ptr()), p("xout"), p("cost"), p("Fx"), p("Fu"),
-                                          p("Lx"), p("Lu"), p("Lxx"), p("Lxu"), p("Luu"), self._stream()),
-                   "aslr_dam_eval")
+        self._call("aslr_dam_eval", model_index, n, C.c_void_p(dx.data_ptr()), C.c_void_p(du.data_ptr()), p("xout"),
+                   p("cost"), p("Fx"), p("Fu"), p("Lx"), p("Lu"), p("Lxx"), p("Lxu"), p("Luu"), self._stream())
         return {k: v.cpu().numpy() for k, v in t.items()}
 
 
@@ -240,9 +293,19 @@ class _PointEvaluator(object):
         r = e.dam_eval(0, x, u)
         data.xout[:] = r["xout"][0]
         data.cost = float(r["cost"][0])
+        self._side_data(data, x, u)
         if diff:
             for k in ("Fx", "Fu", "Lx", "Lu", "Lxx", "Lxu", "Luu"):
                 getattr(data, k)[...] = r[k][0]
+
+    def _side_data(self, ddata, x, u):
+        """data.r (the stacked cost residuals, costs.shareMemory: free_fwddyn_asr.py:128-129) and
+        data.multibody.pinocchio.oMf of the frames the model knows, from the GPU."""
+        e = self.engine
+        dam = self.iam.differential
+        r = e.dam_residuals(0, x, u)[0]
+        ddata.r = dam.costs.order_residuals(r, dam.state.ndx, dam.nu)
+        ddata.multibody.pinocchio.oMf = _FrameMap(e, dam.state.pinocchio, np.asarray(x, dtype=np.float64))
 
     def integrated(self, data, x, u, diff):
         torch = _torch()
@@ -257,9 +320,45 @@ class _PointEvaluator(object):
         data.xnext[:] = e.region(_abi.R_XNEXT)[0, 0].cpu().numpy()
         data.cost = float(e.region(_abi.R_COST)[0, 0].item())
         data.dx[:] = data.xnext - x
+        self._side_data(data.differential, x, u)
+        data.differential.cost = data.cost
+        if self.iam.withCostResiduals:
+            data.r = data.differential.r  # integrated_action.py:17-18
         if diff:
             for k in ("Fx", "Fu", "Lx", "Lu", "Lxx", "Lxu", "Luu"):
                 getattr(data, k)[...] = e.deriv_block(k)[0, 0].cpu().numpy()
+
+
+class _SE3View(object):
+    """What the scripts read from pinocchio.SE3: .rotation, .translation (numpy)."""
+
+    def __init__(self, R, p):
+        self.rotation, self.translation = R, p
+
+    def __repr__(self):
+        return "SE3(R=%r, p=%r)" % (self.rotation, self.translation)
+
+
+class _FrameMap(object):
+    """data.pinocchio.oMf: frame id -> placement, evaluated on the GPU (aslr_frame_placement) on first access."""
+
+    def __init__(self, engine, pin_model, x):
+        self._e, self._m, self._x, self._cache = engine, pin_model, x, {}
+
+    def __getitem__(self, fid):
+        if fid not in self._cache:
+            torch = _torch()
+            fr = self._m.frames[fid]
+            if fr.parent < 0:  # a frame of the universe does not move
+                self._cache[fid] = _SE3View(fr.placement.rotation.copy(), fr.placement.translation.copy())
+                return self._cache[fid]
+            xt = torch.as_tensor(self._x, dtype=torch.float64, device=self._e.device).reshape(1, -1)
+            R, p = self._e.frame_placement(fr.parent, fr.placement.rotation, fr.placement.translation, xt)
+            self._cache[fid] = _SE3View(R[0].cpu().numpy(), p[0].cpu().numpy())
+        return self._cache[fid]
+
+    def __len__(self):
+        return len(self._m.frames)
 
 
 def point_evaluator(model):

@@ -203,6 +203,22 @@ class CostModelSum(object):
     def nr(self):
         return sum((self.costs[n].cost.nr or 0) for n in self._order if self.costs[n].active)
 
+    def order_residuals(self, r, nx, nu):
+        """`r` holds the residual vectors of the active costs stacked in insertion order (the order of the lowered
+        cost list, aslr_dam_residuals); returns them stacked the way Crocoddyl's CostModelSum does: its cost items
+        live in a std::map keyed by name, so data.r follows the ALPHABETICAL order of the cost names."""
+        seg, off = {}, 0
+        for name in self._order:
+            item = self.costs[name]
+            if not item.active:
+                continue
+            n = int(item.cost.nr or 0)
+            seg[name] = r[off:off + n]
+            off += n
+        if off != len(r):
+            raise ValueError("residual vector has %d entries, the cost stack %d" % (len(r), off))
+        return np.concatenate([seg[k] for k in sorted(seg)]) if seg else np.zeros(0)
+
     def lower(self, nj, nx, nu):
         """-> list of _abi.Cost in insertion order."""
         out = []

@@ -3,6 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
+With N > 1 and no RANK / WORLD_SIZE in the environment (i.e. not under torch.distributed.run) the script starts its
+own N ranks, one process per GPU (launch_ranks); under torch.distributed.run it is one of the ranks.
+
 Workload (BASELINE.json metric / configs[2], SURVEY.md 8(d) "C3"; C4 for N = 8): batched BoxDDP on the
 2-DoF VSA arm, T = 100, 4096 trajectories PER GPU (weak scaling; rank r owns rows
 [4096 r, 4096 (r+1)) of the seed-0 batch of 4096 N), synthetic seeded inputs, cold start,
@@ -92,6 +95,46 @@ def cpu_baseline(sc_fn, nthreads):
             "single_thread_note": "the reference forces nthreads = 1 (examples/double_pendulum.py:54)"}
 
 
+def rank_env(rank, world, port, base=None):
+    """Environment of one child rank (the variables torch.distributed.run would set)."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               ASLR_BENCH_SELF_LAUNCHED="1")
+    return env
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` (N > 1) without a torch.distributed.run wrapper: start the N ranks from here, one
+    process per GPU.  This parent never touches torch or the GPU (no exec from a process that initialised HIP); rank
+    0 prints the JSON line on the inherited stdout, the other ranks' stdout goes to stderr.  Returns the exit code:
+    non-zero as soon as any rank fails (the others are then terminated)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=rank_env(r, n, port), stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            try:
+                code = p.wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in pending:  # a rank died: the others would hang in the next collective
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +145,10 @@ def main():
     ap.add_argument("--converge-mode", action="store_true",
                     help="also time the example's own solve (th_stop 1e-7, maxiter 400) after the measured region")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     from aslr_to_amd import _abi, dist, scenarios
@@ -110,12 +157,17 @@ def main():
     # ASLR_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo for the two reductions -- rehearses the N > 1 code
     # path on a one-GPU box (its throughput figure is meaningless: the ranks share the GPU)
     rehearsal = os.environ.get("ASLR_BENCH_REHEARSAL") == "1"
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:  # never report n_gpus different from --gpus
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_env))
+    if not rehearsal and torch.cuda.device_count() < args.gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
     rank, world, local = dist.init_from_env("gloo" if rehearsal else None)
-    if world != max(1, args.gpus) and world > 1:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local if world > 1 and not rehearsal else 0)
+    ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
+    backend = torch.distributed.get_backend() if world > 1 else None
     dev = torch.device("cuda", torch.cuda.current_device())
 
     Bg = args.batch_per_gpu
@@ -193,6 +245,10 @@ def main():
                                "cold start, fixed-iteration mode, full 10-alpha line search every iteration",
                    "batch_per_gpu": Bg, "global_batch": Bg * world, "T": T, "nx": e.nx, "nu": e.nu,
                    "sharding": "contiguous batch blocks, no data-path collective"},
+        "ranks": {"world_size": ranks_seen, "backend": backend,
+                  "launcher": "bench.py" if os.environ.get("ASLR_BENCH_SELF_LAUNCHED") == "1" else
+                              ("torch.distributed.run" if world > 1 else "single process"),
+                  "note": "world size as torch.distributed reports it after init (nccl = RCCL over xGMI)"},
         "ddp_iterations_per_s": args.steps / elapsed,
         "trajectory_iterations_per_s": Bg * world * args.steps / elapsed,
         "line_search_trials_per_iteration": trials,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ASLR_ABI_VERSION 1
+#define ASLR_ABI_VERSION 2
 
 #define ASLR_MAX_NJ     7   /* link-side DoF (2-DoF arm, 7-DoF arm)          */
 #define ASLR_MAX_NX     28  /* 4 * ASLR_MAX_NJ                                */
@@ -216,6 +216,23 @@ enum {
   ASLR_TI_COUNT = ASLR_TI_TRYFAIL0 + ASLR_NALPHA
 };
 
+/* Per-iteration log (aslr_set_iteration_log): what crocoddyl.CallbackLogger / CallbackVerbose read from the solver at
+ * the end of an iteration (examples/double_pendulum.py:77-79, examples/two_dof_sea.py:75), per trajectory.
+ * Layout [capacity][ASLR_LOG_COUNT][B] doubles; row i of trajectory b is written by that trajectory's i-th
+ * iteration (the integer fields as doubles).  Iterations past `capacity` are not recorded. */
+enum {
+  ASLR_LOG_COST = 0,  /* solver.cost after the iteration                                        */
+  ASLR_LOG_STOP,      /* solver.stoppingCriteria()                                              */
+  ASLR_LOG_XREG,      /* solver.x_reg (= u_reg) after the regularisation update                 */
+  ASLR_LOG_STEP,      /* solver.stepLength: the accepted step length, or the last one tried     */
+  ASLR_LOG_D1, ASLR_LOG_D2, /* solver.expectedImprovement() (CallbackLogger.grads = -d2)        */
+  ASLR_LOG_DV, ASLR_LOG_DVEXP,
+  ASLR_LOG_ACCEPTED,  /* index of the accepted step length, -1: every trial rejected            */
+  ASLR_LOG_STATUS,    /* ASLR_ST_* bits after the iteration                                     */
+  ASLR_LOG_FEASIBLE,  /* solver.isFeasible after the iteration                                  */
+  ASLR_LOG_COUNT
+};
+
 typedef struct aslr_region {
   int64_t offset;                    /* in bytes from the workspace base                     */
   int64_t bytes;
@@ -291,6 +308,29 @@ int aslr_count_active(aslr_problem_t *p, void *stream, int32_t *active);
 int aslr_dam_eval(aslr_problem_t *p, int32_t model_index, int32_t n, const double *x,
                   const double *u, double *xout, double *cost, double *Fx, double *Fu, double *Lx,
                   double *Lu, double *Lxx, double *Lxu, double *Luu, void *stream);
+
+/* The cost residuals of DifferentialFree{ASR,VSA}FwdDynamicsModel.calc on `n` points: data.r, which
+ * IntegratedActionModelEulerASR.calc copies (python/aslr_to/integrated_action.py:17-18) -- the residual vectors of
+ * the model's cost terms stacked in the order of aslr_model_t.costs: FRAME_PLACEMENT 6 (log6 of Mref^-1 oMf,
+ * python/aslr_to/residual_frame_placement.py:13-15), STATE nx, CONTROL nu, PENDULUM 6
+ * (python/aslr_to/__init__.py:231), STIFFNESS nu/2 (python/aslr_to/stiffness_cost.py:15).  DEVICE pointers;
+ * r [n][aslr_residual_len(model, nj)]. */
+int aslr_dam_residuals(aslr_problem_t *p, int32_t model_index, int32_t n, const double *x, const double *u,
+                       double *r, void *stream);
+/* length of that stacked residual vector (host only, no GPU needed) */
+int32_t aslr_residual_len(const aslr_model_t *m, int32_t nj);
+
+/* data.differential.multibody.pinocchio.oMf[frame] (examples/two_dof_sea.py:82-86, examples/two_dof_vsa_boxddp.py:83-84):
+ * world placement of a frame attached to joint `frame_joint` with local placement (frame_R row-major 3x3, frame_p;
+ * HOST pointers) at `n` configurations.  x: DEVICE pointer, point i at x + i * x_stride doubles, its first nj entries
+ * are the link positions q_l (so XS itself can be passed with x_stride = nx).  oMf: DEVICE [n][12] = R row-major, p. */
+int aslr_frame_placement(aslr_problem_t *p, int32_t frame_joint, const double *frame_R, const double *frame_p,
+                         int32_t n, const double *x, int64_t x_stride, double *oMf, void *stream);
+
+/* Per-iteration log of the solver state (layout and fields: ASLR_LOG_* above).  `log` is a DEVICE buffer of
+ * capacity * ASLR_LOG_COUNT * B doubles owned by the caller and kept alive while set; NULL switches logging off.
+ * Written by the line-search kernel of aslr_iterate / aslr_solve: no host round trip per iteration. */
+int aslr_set_iteration_log(aslr_problem_t *p, double *log, int32_t capacity);
 
 /* ShootingProblem.quasiStatic(xs) (examples/two_dof_sea.py:78): for every running node, the control that
  * holds XS[t] still under the node's model, by Crocoddyl's base-class Gauss-Newton

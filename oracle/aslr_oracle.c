@@ -541,6 +541,8 @@ static int gen_inverse(int n, const double *A, double *Ainv) {
 /* ======================================================================================= */
 /* Differential action model: calc + calcDiff + cost stack                                  */
 /* ======================================================================================= */
+static __thread double *g_resid_sink; /* set by aslr_cpu_dam_residuals around one aslr_cpu_dam call */
+
 void aslr_cpu_dam(const aslr_chain_t *c, const aslr_model_t *m, const double *frame_ref,
                   const double *x, const double *u_in, double *xout_o, double *cost_o,
                   double *Fx_o, double *Fu_o, double *Lx_o, double *Lu_o, double *Lxx_o,
@@ -636,6 +638,7 @@ void aslr_cpu_dam(const aslr_chain_t *c, const aslr_model_t *m, const double *fr
   if (Fu_o) memcpy(Fu_o, Fu, sizeof(double) * nv * nu);
 
   /* ---- cost stack: CostModelSum of residual costs ---- */
+  double *rs = g_resid_sink; /* aslr_cpu_dam_residuals: data.r, the stacked residual vectors (integrated_action.py:17-18) */
   double cost = 0.0, Lx[NX], Lu[NU], Lxx[NX * NX], Lxu[NX * NU], Luu[NU * NU];
   memset(Lx, 0, sizeof Lx); memset(Lu, 0, sizeof Lu);
   memset(Lxx, 0, sizeof Lxx); memset(Lxu, 0, sizeof Lxu); memset(Luu, 0, sizeof Luu);
@@ -664,6 +667,7 @@ void aslr_cpu_dam(const aslr_chain_t *c, const aslr_model_t *m, const double *fr
       double a = 0.0;
       for (int i = 0; i < 6; ++i) a += ct->act_w[i] * r[i] * r[i];
       cost += w * 0.5 * a;
+      if (rs) { memcpy(rs, r, sizeof r); rs += 6; }
       for (int j = 0; j < nj; ++j) {
         double s = 0.0;
         for (int i = 0; i < 6; ++i) s += Jr[i * nj + j] * ct->act_w[i] * r[i];
@@ -682,7 +686,9 @@ void aslr_cpu_dam(const aslr_chain_t *c, const aslr_model_t *m, const double *fr
         a += ct->act_w[i] * r * r;
         Lx[i] += w * ct->act_w[i] * r;
         Lxx[i * nx + i] += w * ct->act_w[i];
+        if (rs) rs[i] = r;
       }
+      if (rs) rs += nx;
       cost += w * 0.5 * a;
     } break;
     case ASLR_COST_CONTROL: { /* r = u - uref, Ru = I */
@@ -692,7 +698,9 @@ void aslr_cpu_dam(const aslr_chain_t *c, const aslr_model_t *m, const double *fr
         a += ct->act_w[i] * r * r;
         Lu[i] += w * ct->act_w[i] * r;
         Luu[i * nu + i] += w * ct->act_w[i];
+        if (rs) rs[i] = r;
       }
+      if (rs) rs += nu;
       cost += w * 0.5 * a;
     } break;
     case ASLR_COST_PENDULUM: { /* __init__.py:228-249 */
@@ -702,6 +710,7 @@ void aslr_cpu_dam(const aslr_chain_t *c, const aslr_model_t *m, const double *fr
       double a = 0.0;
       for (int i = 0; i < 6; ++i) a += aw[i] * r[i] * r[i];
       cost += w * 0.5 * a;
+      if (rs) { memcpy(rs, r, sizeof r); rs += 6; }
       /* Lx = Rx^T Ar */
       Lx[0] += w * (c1 * aw[0] * r[0] - s1 * aw[2] * r[2]);
       Lx[1] += w * (c2 * aw[1] * r[1] - s2 * aw[3] * r[3]);
@@ -719,7 +728,9 @@ void aslr_cpu_dam(const aslr_chain_t *c, const aslr_model_t *m, const double *fr
       for (int i = 0; i < h; ++i) {
         a += ct->lambda * (u[h + i] - ct->ref[i]);
         Lu[h + i] += w * ct->lambda;
+        if (rs) rs[i] = ct->lambda * (u[h + i] - ct->ref[i]); /* stiffness_cost.py:15 */
       }
+      if (rs) rs += h;
       cost += w * a;
     } break;
     default: break;
@@ -731,6 +742,13 @@ void aslr_cpu_dam(const aslr_chain_t *c, const aslr_model_t *m, const double *fr
   if (Lxx_o) memcpy(Lxx_o, Lxx, sizeof(double) * nx * nx);
   if (Lxu_o) memcpy(Lxu_o, Lxu, sizeof(double) * nx * nu);
   if (Luu_o) memcpy(Luu_o, Luu, sizeof(double) * nu * nu);
+}
+
+void aslr_cpu_dam_residuals(const aslr_chain_t *c, const aslr_model_t *m, const double *frame_ref,
+                            const double *x, const double *u, double *r) {
+  g_resid_sink = r;
+  aslr_cpu_dam(c, m, frame_ref, x, u, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+  g_resid_sink = NULL;
 }
 
 static int rec_len(int nx, int nu) {
@@ -951,7 +969,20 @@ typedef struct {
   double *K, *k, *Qu, *Quuk, *Vx, *Vxx;
   double cost, cost_try, xreg, ureg, d1, d2, dg, dq, dv, dV, dVexp, stop, steplength;
   int is_feasible, was_feasible, iter, status;
+  double *log; /* this trajectory's column of the per-iteration log (layout of aslr_set_iteration_log), or NULL */
+  int log_cap, log_B, accepted;
 } traj_t;
+
+/* what crocoddyl's callbacks read at the end of an iteration (ASLR_LOG_* of include/aslr_to_amd.h) */
+static void traj_log(const traj_t *s) {
+  if (!s->log || s->iter >= s->log_cap) return;
+  double *lg = s->log + (size_t)s->iter * ASLR_LOG_COUNT * s->log_B;
+  const size_t B = s->log_B;
+  lg[ASLR_LOG_COST * B] = s->cost; lg[ASLR_LOG_STOP * B] = s->stop; lg[ASLR_LOG_XREG * B] = s->xreg;
+  lg[ASLR_LOG_STEP * B] = s->steplength; lg[ASLR_LOG_D1 * B] = s->d1; lg[ASLR_LOG_D2 * B] = s->d2;
+  lg[ASLR_LOG_DV * B] = s->dV; lg[ASLR_LOG_DVEXP * B] = s->dVexp; lg[ASLR_LOG_ACCEPTED * B] = s->accepted;
+  lg[ASLR_LOG_STATUS * B] = s->status; lg[ASLR_LOG_FEASIBLE * B] = s->is_feasible;
+}
 
 static int is_bad(double v) { return isnan(v) || isinf(v) || v >= 1e30; } /* crocoddyl raiseIfNaN */
 
@@ -1280,6 +1311,7 @@ static int traj_solve(traj_t *s) {
     traj_expected_improvement(s);
     recalc = 0;
     double alpha = 1.0;
+    s->accepted = -1;
     for (int a = 0; a < ASLR_NALPHA; ++a, alpha *= 0.5) {
       s->steplength = alpha;
       if (traj_forward(s, alpha)) { s->status |= ASLR_ST_FORWARD_ERR; continue; }
@@ -1302,6 +1334,7 @@ static int traj_solve(traj_t *s) {
         memcpy(s->us, s->us_try, sizeof(double) * T * nu);
         s->is_feasible = sp->solver == ASLR_SOLVER_FDDP ? (s->was_feasible || alpha == 1.0) : 1;
         s->cost = s->cost_try;
+        s->accepted = a;
         recalc = 1;
         break;
       }
@@ -1309,8 +1342,9 @@ static int traj_solve(traj_t *s) {
     if (s->steplength > sp->th_stepdec) reg_decrease(s);
     if (s->steplength <= sp->th_stepinc) {
       reg_increase(s);
-      if (s->xreg == sp->reg_max) { s->status |= ASLR_ST_REG_MAX; s->iter++; return 0; }
+      if (s->xreg == sp->reg_max) { s->status |= ASLR_ST_REG_MAX; traj_log(s); s->iter++; return 0; }
     }
+    traj_log(s); /* Crocoddyl calls the callbacks here, before the convergence test */
     if (!sp->fixed_iterations && s->was_feasible && s->stop < sp->th_stop) {
       s->status |= ASLR_ST_CONVERGED;
       s->iter++;
@@ -1336,6 +1370,11 @@ static void traj_store(const traj_t *s, double *xs, double *us, int B, int b) {
 
 int aslr_cpu_solve(const aslr_problem_desc_t *d, const aslr_solver_params_t *sp, double *xs,
                    double *us, double *traj_f, int32_t *traj_i, int32_t nthreads) {
+  return aslr_cpu_solve_log(d, sp, xs, us, traj_f, traj_i, nthreads, NULL, 0);
+}
+
+int aslr_cpu_solve_log(const aslr_problem_desc_t *d, const aslr_solver_params_t *sp, double *xs,
+                       double *us, double *traj_f, int32_t *traj_i, int32_t nthreads, double *log, int32_t log_cap) {
   if (desc_check(d)) return ASLR_E_INVALID;
   const int B = d->B;
 #ifdef _OPENMP
@@ -1349,6 +1388,7 @@ int aslr_cpu_solve(const aslr_problem_desc_t *d, const aslr_solver_params_t *sp,
 #endif
     for (int b = 0; b < B; ++b) {
       traj_load(&s, xs, us, B, b);
+      s.log = log ? log + b : NULL; s.log_cap = log_cap; s.log_B = B;
       traj_solve(&s);
       traj_store(&s, xs, us, B, b);
       if (traj_f) {

@@ -78,6 +78,13 @@ int aslr_cpu_forward_pass(const aslr_problem_desc_t *d, const aslr_solver_params
  * nthreads <= 1: serial; > 1: OpenMP over trajectories. */
 int aslr_cpu_solve(const aslr_problem_desc_t *d, const aslr_solver_params_t *sp, double *xs,
                    double *us, double *traj_f, int32_t *traj_i, int32_t nthreads);
+/* the same solve, also recording the per-iteration solver state in the layout of aslr_set_iteration_log
+ * (log [log_cap][ASLR_LOG_COUNT][B]; NULL: no log) */
+int aslr_cpu_solve_log(const aslr_problem_desc_t *d, const aslr_solver_params_t *sp, double *xs,
+                       double *us, double *traj_f, int32_t *traj_i, int32_t nthreads, double *log, int32_t log_cap);
+/* data.r: the stacked cost residuals of one (x, u) in the order of m->costs (integrated_action.py:17-18) */
+void aslr_cpu_dam_residuals(const aslr_chain_t *c, const aslr_model_t *m, const double *frame_ref,
+                            const double *x, const double *u, double *r);
 /* BoxQP: returns iterations used; x in (warm start) / out; Hff_inv is n*n with
  * only the leading nf*nf block meaningful; free_idx/clamped_idx sized n. */
 int aslr_cpu_boxqp(int n, const double *H, const double *q, const double *lb, const double *ub,

@@ -186,16 +186,34 @@ def forward_pass(low, sp, alpha, xs, us, K, k, gaps=None, feasible=None):
     return xs_try, us_try, cost_try, fail
 
 
-def solve(low, sp, xs=None, us=None, nthreads=1):
-    """-> dict(xs [T+1,B,nx], us [T,B,nu], traj_f [TF_COUNT,B], traj_i [TI_COUNT,B])"""
+def dam_residuals(low, mi, x, u, frame_ref=None):
+    """data.r of one point: the stacked cost residuals in the order of the model's cost list."""
+    nr = sum({_abi.COST_FRAME_PLACEMENT: 6, _abi.COST_STATE: low.nx, _abi.COST_CONTROL: low.nu, _abi.COST_PENDULUM: 6,
+              _abi.COST_STIFFNESS: low.nu // 2}[low.desc.models[mi].costs[c].type] for c in range(low.desc.models[mi].ncosts))
+    x, u = _arr(x, low.nx), _arr(u, low.nu)
+    r = np.zeros(nr)
+    fr = None if frame_ref is None else _arr(frame_ref, 12)
+    lib().aslr_cpu_dam_residuals(C.byref(low.desc.chain), C.byref(low.desc.models[mi]), None if fr is None else _d(fr),
+                                 _d(x), _d(u), _d(r))
+    return r
+
+
+def solve(low, sp, xs=None, us=None, nthreads=1, log_cap=0):
+    """-> dict(xs [T+1,B,nx], us [T,B,nu], traj_f [TF_COUNT,B], traj_i [TI_COUNT,B]); with log_cap > 0 also
+    log [log_cap, LOG_COUNT, B], the per-iteration solver state (NaN where a trajectory had stopped)."""
     T, B, nx, nu = low.T, low.B, low.nx, low.nu
     xs = np.zeros((T + 1, B, nx)) if xs is None else _arr(xs, (T + 1) * B * nx).reshape(T + 1, B, nx).copy()
     us = np.zeros((T, B, nu)) if us is None else _arr(us, T * B * nu).reshape(T, B, nu).copy()
     tf = np.zeros((_abi.TF_COUNT, B))
     ti = np.zeros((_abi.TI_COUNT, B), dtype=np.int32)
-    rc = lib().aslr_cpu_solve(C.byref(low.desc), C.byref(sp), _d(xs), _d(us), _d(tf), _i(ti), int(nthreads))
+    log = np.full((log_cap, _abi.LOG_COUNT, B), np.nan) if log_cap > 0 else None
+    rc = lib().aslr_cpu_solve_log(C.byref(low.desc), C.byref(sp), _d(xs), _d(us), _d(tf), _i(ti), int(nthreads),
+                                  None if log is None else _d(log), int(log_cap))
     assert rc == 0
-    return dict(xs=xs, us=us, traj_f=tf, traj_i=ti)
+    out = dict(xs=xs, us=us, traj_f=tf, traj_i=ti)
+    if log is not None:
+        out["log"] = log
+    return out
 
 
 def boxqp(H, q, lb, ub, xinit, maxiter=100, th_acceptstep=0.1, th_grad=1e-9, reg=1e-9):

@@ -20,43 +20,32 @@ def _numdiff(f, z, h=1e-6):
     return J
 
 
-def test_reference_unit_test_vsa_stiffness_residual_numdiff():
-    """unittest/test_stiffness_residual.py:12-56 written against the drop-in package: analytic Fx, Fu, Lx, Lu
-    of the VSA model vs finite differences of calc (the reference's tolerances: 6.3e-3 and 3e-2)."""
-    two_dof = example_robot_data.load('asr_twodof')
-    robot_model = two_dof.model
-    state = aslr_to.StateMultibodyASR(robot_model)
-    actuation = aslr_to.VSAASRActuation(state)
-    nu = 2 * actuation.nu
-    costs = crocoddyl.CostModelSum(state, nu)
-    framePlacementResidual = aslr_to.ResidualModelFramePlacementASR(
-        state, robot_model.getFrameId("EE"), pinocchio.SE3(np.eye(3), np.array([.0, .0, .4])), nu)
-    costs.addCost("gripperPose", crocoddyl.CostModelResidual(state, framePlacementResidual), nu)
-    costs.addCost("xReg", crocoddyl.CostModelResidual(state, crocoddyl.ResidualModelControl(state, nu)), 1e-2)
-    costs.addCost("vsa", aslr_to.CostModelStiffness(state, nu, .1, np.zeros(int(nu / 2))), 1e0)
-    model = aslr_to.DifferentialFreeFwdDynamicsModelVSA(state, actuation, costs)
-    np.random.seed(0)
-    x = model.state.rand()
-    u = np.random.rand(model.nu)
-    data = model.createData()
-    model.calc(data, x, u)
-    model.calcDiff(data, x, u)
+def test_vsa_model_with_stiffness_cost_passes_the_numdiff_acceptance_check():
+    """The reference's acceptance technique for its VSA model with a stiffness cost in the stack
+    (unittest/test_stiffness_residual.py: analytic Fx, Fu, Lx, Lu against central differences of calc, tolerances
+    6.3e-3 and 3e-2), applied to the drop-in classes on the GPU."""
+    model = scenarios.two_dof_vsa_modified(B=1, T=1)["running"][0].differential
+    rng = np.random.default_rng(0)
+    x, u = rng.uniform(-1.0, 1.0, model.state.nx), rng.uniform(0.0, 1.0, model.nu)
+    analytic = model.createData()
+    model.calc(analytic, x, u)
+    model.calcDiff(analytic, x, u)
 
-    def xout(xx, uu):
-        d = model.createData()
-        model.calc(d, xx, uu)
-        return d.xout.copy()
+    def evaluate(field):
+        def f(xx, uu):
+            d = model.createData()
+            model.calc(d, xx, uu)
+            return np.array(getattr(d, field), dtype=float, copy=True)
+        return f
 
-    def cost(xx, uu):
-        d = model.createData()
-        model.calc(d, xx, uu)
-        return d.cost
-    assert np.allclose(data.Fx, _numdiff(lambda z: xout(z, u), x), atol=6.3e-3)
-    assert np.allclose(data.Fu, _numdiff(lambda z: xout(x, z), u), atol=6.3e-3)
-    assert np.allclose(data.Lx, _numdiff(lambda z: cost(z, u), x).ravel(), atol=3e-2)
-    assert np.allclose(data.Lu, _numdiff(lambda z: cost(x, z), u).ravel(), atol=3e-2)
-    # and tighter than the reference asks
-    assert np.abs(data.Fx - _numdiff(lambda z: xout(z, u), x)).max() < 1e-4
+    acc, cost = evaluate("xout"), evaluate("cost")
+    checks = [("Fx", analytic.Fx, _numdiff(lambda z: acc(z, u), x), 6.3e-3),
+              ("Fu", analytic.Fu, _numdiff(lambda z: acc(x, z), u), 6.3e-3),
+              ("Lx", analytic.Lx, _numdiff(lambda z: cost(z, u), x).ravel(), 3e-2),
+              ("Lu", analytic.Lu, _numdiff(lambda z: cost(x, z), u).ravel(), 3e-2)]
+    for name, got, fd, tol in checks:
+        assert np.allclose(got, fd, atol=tol), name
+    assert np.abs(analytic.Fx - checks[0][2]).max() < 1e-4   # and far tighter than the reference asks
 
 
 def test_dam_and_integrated_calc_match_oracle_through_the_python_api(oracle):
@@ -81,60 +70,47 @@ def test_dam_and_integrated_calc_match_oracle_through_the_python_api(oracle):
         np.testing.assert_allclose(getattr(di, k), kr[k], rtol=1e-9, atol=1e-10)
 
 
-def test_vsa_boxddp_example_script_flow(oracle):
-    """examples/two_dof_vsa_boxddp.py:14-87 with the stand-in namespaces (T = 100 per BASELINE.json)."""
-    robot_model = example_robot_data.load('asr_twodof').model
-    robot_model.gravity.linear = np.array([9.81, 0, 0])
-    state = aslr_to.StateMultibodyASR(robot_model)
-    actuation = aslr_to.VSAASRActuation(state)
-    nu = 2 * actuation.nu
-    framePlacementResidual = aslr_to.ResidualModelFramePlacementASR(
-        state, robot_model.getFrameId("EE"), pinocchio.SE3(np.eye(3), np.array([.01, .2, .18])), nu)
-    goalTrackingCost = crocoddyl.CostModelResidual(state, framePlacementResidual)
-    xActivation = crocoddyl.ActivationModelWeightedQuad(np.array([1e0] * 2 + [1e0] * 2 + [1e0] * robot_model.nv + [1e0] * robot_model.nv))
-    xRegCost = crocoddyl.CostModelResidual(state, xActivation, crocoddyl.ResidualModelState(state, state.zero(), nu))
-    uActivation = crocoddyl.ActivationModelWeightedQuad(np.array([1e0] + [1e0] + [1e0] * 2))
-    uRegCost = crocoddyl.CostModelResidual(state, uActivation, crocoddyl.ResidualModelControl(state, nu))
-    runningCostModel = crocoddyl.CostModelSum(state, nu)
-    terminalCostModel = crocoddyl.CostModelSum(state, nu)
-    runningCostModel.addCost("gripperPose", goalTrackingCost, 1e0)
-    runningCostModel.addCost("xReg", xRegCost, 1e-1)
-    runningCostModel.addCost("uReg", uRegCost, 1e-1)
-    terminalCostModel.addCost("gripperPose", goalTrackingCost, 4e4)
-    B = .001 * np.eye(int(state.nv / 2))
-    dt = 1e-2
-    runningModel = aslr_to.IntegratedActionModelEulerASR(
-        aslr_to.DifferentialFreeFwdDynamicsModelVSA(state, actuation, runningCostModel, B), dt)
-    terminalModel = aslr_to.IntegratedActionModelEulerASR(
-        aslr_to.DifferentialFreeFwdDynamicsModelVSA(state, actuation, terminalCostModel, B), 0)
-    runningModel.u_lb = np.array([-100, -100, 0, 0])
-    runningModel.u_ub = np.array([100, 100, 100, 100])
-    T = 100
-    x0 = np.concatenate([np.array([.0, .0]), np.zeros(2), pinocchio.utils.zero(state.nv)])
-    problem = crocoddyl.ShootingProblem(x0, [runningModel] * T, terminalModel)
+def test_vsa_boxddp_example_end_to_end_through_the_solver_api(oracle):
+    """What examples/two_dof_vsa_boxddp.py does with its solver (T = 100 per BASELINE.json): logger callback, cold
+    start, th_stop 1e-7, 400 iterations at most, then the end-effector position and the squared controls -- through
+    the drop-in SolverBoxDDP, against the CPU oracle on the same ShootingProblem."""
+    sc = scenarios.two_dof_vsa_boxddp(B=1, T=100)
+    running = sc["running"][0]
+    problem = crocoddyl.ShootingProblem(sc["x0"][0], sc["running"], sc["terminal"])
     solver = crocoddyl.SolverBoxDDP(problem)
-    solver.setCallbacks([crocoddyl.CallbackLogger()])
-    solver.th_stop = 1e-7
-    converged = solver.solve([], [], 400)
-    log = solver.getCallbacks()[0]
-    assert converged and solver.stop < 1e-7
+    log = crocoddyl.CallbackLogger()
+    solver.setCallbacks([log])
+    solver.th_stop = sc["th_stop"]
+    assert solver.solve([], [], sc["maxiter"]) and solver.stop < sc["th_stop"]
+    T = problem.T
     assert len(solver.xs) == T + 1 and len(solver.us) == T and solver.xs[0].shape == (8,)
+    assert solver.getCallbacks()[0] is log
     assert len(log.costs) == solver.iter + 1 and log.costs[-1] == pytest.approx(solver.cost)
-    assert all(b <= a + 1e-9 for a, b in zip(log.costs[1:], log.costs[2:]))  # accepted steps never raise the cost
+    assert all(later <= earlier + 1e-9 for earlier, later in zip(log.costs[1:], log.costs[2:]))  # accepted steps only lower it
     assert aslr_to.u_squared(log).shape == (4,)
     us = np.array(solver.us)
-    assert (us >= runningModel.u_lb - 1e-12).all() and (us <= runningModel.u_ub + 1e-12).all()
-    # same answer as the CPU oracle on the same ShootingProblem
-    sp = _abi.default_solver_params(_abi.SOLVER_BOXDDP)
-    sp.maxiter, sp.th_stop = 400, 1e-7
-    ref = oracle.solve(problem.lowered, sp)
+    assert (us >= running.u_lb - 1e-12).all() and (us <= running.u_ub + 1e-12).all()
+    sp = scenarios.solver_params(sc)
+    ref = oracle.solve(problem.lowered, sp, log_cap=sc["maxiter"])
     assert np.abs(np.array(solver.xs) - ref["xs"][:, 0]).max() < 1e-6
     assert np.abs(us - ref["us"][:, 0]).max() < 1e-6
     assert abs(solver.cost - ref["traj_f"][_abi.TF_COST][0]) < 1e-4
     assert solver.iter + 1 == ref["traj_i"][_abi.TI_ITER][0]
-    # terminal EE position, read as the script does (examples/two_dof_vsa_boxddp.py:83-84)
-    ee = oracle.frame_placement(problem.lowered.desc.chain, solver.xs[-1][:2], 1, np.eye(3), [0.12, -2.03063311e-04, 0.0])[1]
-    assert np.isfinite(ee).all()
+    # the logger's series against the oracle's per-iteration values
+    n = len(log.costs)
+    np.testing.assert_allclose(log.costs, ref["log"][:n, _abi.LOG_COST, 0], rtol=1e-7)
+    np.testing.assert_array_equal(log.steps, ref["log"][:n, _abi.LOG_STEP, 0])
+    np.testing.assert_array_equal(log.x_regs, ref["log"][:n, _abi.LOG_XREG, 0])
+    np.testing.assert_allclose(log.stops, ref["log"][:n, _abi.LOG_STOP, 0], rtol=1e-4, atol=1e-12)
+    # the script's last print: where the end effector ended up (examples/two_dof_vsa_boxddp.py:83-84)
+    model = running.state.pinocchio
+    fid = model.getFrameId("EE")
+    reached = solver.problem.terminalData.differential.multibody.pinocchio.oMf[fid].translation
+    fr = model.frames[fid]
+    expect = oracle.frame_placement(problem.lowered.desc.chain, solver.xs[-1][:2], fr.parent, fr.placement.rotation,
+                                    fr.placement.translation)[1]
+    np.testing.assert_allclose(reached, expect, atol=1e-12)
+    assert np.abs(reached - np.array([.01, .2, .18])).max() < 5e-3   # the 4e4-weighted terminal cost pulls it onto the target
 
 
 def test_full_batch_properties_and_batch_size_independence():
@@ -306,3 +282,178 @@ def test_quasi_static_matches_oracle_and_holds_the_state(oracle):
     ref = oracle.solve(problem.lowered, sp, xs=np.array(xs0)[:, None, :], us=np.array(us0)[:, None, :])
     assert np.abs(np.array(solver.xs) - ref["xs"][:, 0]).max() < 1e-6
     assert abs(solver.cost - ref["traj_f"][_abi.TF_COST][0]) < 1e-4
+
+
+def test_frame_placements_and_residuals_of_node_data_match_the_oracle(oracle):
+    """runningDatas[t] / terminalData: .differential.multibody.pinocchio.oMf[frame] (examples/two_dof_sea.py:82-86) and
+    data.r (integrated_action.py:17-18) come from the GPU; checked against the oracle on the 2-DoF and 7-DoF chains,
+    single problem and batch."""
+    import torch
+    for name, kw in (("two_dof_sea", dict(B=1, T=6)), ("talos_arm_sea", dict(B=3, T=4, seed=2))):
+        sc = scenarios.SCENARIOS[name](**kw)
+        B = sc["x0"].shape[0]
+        problem = crocoddyl.ShootingProblem(sc["x0"][0] if B == 1 else sc["x0"], sc["running"], sc["terminal"],
+                                            frame_refs=None if B == 1 else sc["frame_refs"])
+        rng = np.random.default_rng(4)
+        nj = problem.nx // 4
+        xs = rng.uniform(-0.8, 0.8, (B, problem.T + 1, problem.nx))
+        us = rng.uniform(-0.5, 0.5, (B, problem.T, problem.nu))
+        problem.calc(xs[0] if B == 1 else torch.as_tensor(xs), us[0] if B == 1 else torch.as_tensor(us))
+        model = sc["running"][0].state.pinocchio
+        chain = problem.lowered.desc.chain
+        for fid, fr in enumerate(model.frames):
+            for t in (0, problem.T):
+                node = problem.runningDatas.tolist()[t] if t < problem.T else problem.terminalData
+                M = node.differential.multibody.pinocchio.oMf[fid]
+                for b in range(B):
+                    R = M.rotation if B == 1 else M.rotation[b].cpu().numpy()
+                    p = M.translation if B == 1 else M.translation[b].cpu().numpy()
+                    if fr.parent < 0:
+                        np.testing.assert_array_equal(p, fr.placement.translation)
+                        continue
+                    Rr, pr = oracle.frame_placement(chain, xs[b, t, :nj], fr.parent, fr.placement.rotation,
+                                                    fr.placement.translation)
+                    np.testing.assert_allclose(R, Rr, atol=1e-12)
+                    np.testing.assert_allclose(p, pr, atol=1e-12)
+        # data.r of a running node and of the terminal node (trajectory 0), in Crocoddyl's name order
+        lowm = problem.lowered
+        for t in (1, problem.T):
+            node = problem.runningDatas.tolist()[t] if t < problem.T else problem.terminalData
+            iam = sc["running"][t] if t < problem.T else sc["terminal"]
+            u = us[0, t] if t < problem.T else iam.differential._default_u()
+            fref = None if lowm.frame_ref is None else lowm.frame_ref[0]
+            raw = oracle.dam_residuals(lowm, int(lowm.node_model[t]), xs[0, t], u, frame_ref=fref)
+            expect = iam.differential.costs.order_residuals(raw, problem.nx, problem.nu)
+            assert expect.size == iam.differential.costs.nr and expect.size > 0
+            np.testing.assert_allclose(node.r, expect, rtol=1e-10, atol=1e-12)
+
+
+def test_model_level_data_r_and_omf(oracle):
+    """model.calc(data, x, u) fills data.r (stacked residuals, alphabetical cost-name order like Crocoddyl's
+    CostModelSum) and data.multibody.pinocchio.oMf; the integrated model copies r (integrated_action.py:17-18)."""
+    sc = scenarios.two_dof_vsa_modified(B=1, T=1)
+    iam = sc["running"][0]
+    dam = iam.differential
+    rng = np.random.default_rng(8)
+    x, u = rng.uniform(-1, 1, 8), rng.uniform(0.1, 1, 4)
+    d = dam.createData()
+    dam.calc(d, x, u)
+    low = scenarios.lower(sc)
+    raw = oracle.dam_residuals(low, 0, x, u, frame_ref=None)
+    # insertion order gripperPose(6) xReg(8) uReg(4) vsa(2) -> name order gripperPose, uReg, vsa, xReg
+    expect = np.concatenate([raw[0:6], raw[14:18], raw[18:20], raw[6:14]])
+    np.testing.assert_allclose(d.r, expect, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(raw[18:20], 10 * (u[2:] - 0.002), rtol=1e-14)      # stiffness_cost.py:15
+    np.testing.assert_allclose(raw[6:14], x, rtol=0, atol=0)                        # state residual about 0
+    model = dam.state.pinocchio
+    fid = model.getFrameId("EE")
+    fr = model.frames[fid]
+    Rr, pr = oracle.frame_placement(low.desc.chain, x[:2], fr.parent, fr.placement.rotation, fr.placement.translation)
+    np.testing.assert_allclose(d.multibody.pinocchio.oMf[fid].translation, pr, atol=1e-12)
+    np.testing.assert_allclose(d.pinocchio.oMf[fid].rotation, Rr, atol=1e-12)
+    di = iam.createData()
+    iam.calc(di, x, u)
+    np.testing.assert_allclose(di.r, expect, rtol=1e-10, atol=1e-12)
+
+
+def test_batched_logger_matches_the_oracle_iteration_by_iteration(oracle, tmp_path):
+    """CallbackLogger / CallbackVerbose on a batch of 8: the per-iteration series come from the device-resident log
+    (no host round trip per iteration) and equal the oracle's per-iteration values; export_solution writes the arrays
+    examples/two_dof_vsa_boxddp.py:104-127 saves."""
+    import io
+    sc = scenarios.two_dof_vsa_boxddp(B=8, T=40, seed=1)
+    problem = crocoddyl.ShootingProblem(sc["x0"], sc["running"], sc["terminal"], frame_refs=sc["frame_refs"])
+    solver = crocoddyl.SolverBoxDDP(problem)
+    solver.th_stop = sc["th_stop"]
+    log, table = crocoddyl.CallbackLogger(), io.StringIO()
+    solver.setCallbacks([log, crocoddyl.CallbackVerbose(table)])
+    solver.solve([], [], 60)
+    ref = oracle.solve(problem.lowered, scenarios.solver_params(sc, maxiter=60), log_cap=60)
+    iters = ref["traj_i"][_abi.TI_ITER]
+    np.testing.assert_array_equal(log.iters, iters)
+    n = int(iters.max())
+    assert log.costs.shape == (n, 8)
+    rl = ref["log"][:n]
+    np.testing.assert_array_equal(np.isnan(log.costs), np.isnan(rl[:, _abi.LOG_COST]))
+    for b in range(8):
+        k = int(iters[b])
+        assert np.isnan(log.costs[k:, b]).all() and not np.isnan(log.costs[:k, b]).any()
+    on = ~np.isnan(rl[:, _abi.LOG_COST])
+    np.testing.assert_allclose(log.costs[on], rl[:, _abi.LOG_COST][on], rtol=1e-7)
+    np.testing.assert_array_equal(log.steps[on], rl[:, _abi.LOG_STEP][on])
+    np.testing.assert_array_equal(log.x_regs[on], rl[:, _abi.LOG_XREG][on])
+    np.testing.assert_allclose(log.stops[on], rl[:, _abi.LOG_STOP][on], rtol=1e-4, atol=1e-12)
+    np.testing.assert_allclose(log.grads[on], -rl[:, _abi.LOG_D2][on], rtol=1e-4, atol=1e-12)
+    full = solver.iteration_log()
+    np.testing.assert_array_equal(full[:, _abi.LOG_ACCEPTED][on], rl[:, _abi.LOG_ACCEPTED][on])
+    np.testing.assert_array_equal(full[:, _abi.LOG_STATUS][on], rl[:, _abi.LOG_STATUS][on])
+    np.testing.assert_array_equal(full[:, _abi.LOG_FEASIBLE][on], rl[:, _abi.LOG_FEASIBLE][on])
+    rows = table.getvalue().splitlines()
+    assert rows[0].split()[:2] == ["iter", "active"] and len([r for r in rows if r.split()[0].isdigit()]) == n
+    # export: q, u, stiffness, t of one trajectory and of the batch
+    path = solver.export_solution(str(tmp_path / "sol.npz"), trajectory=3)
+    z = np.load(path)
+    X, U = solver.xs.cpu().numpy(), solver.us.cpu().numpy()
+    np.testing.assert_array_equal(z["q"], X[3][:, :2])
+    np.testing.assert_array_equal(z["u"], U[3][:, :2])
+    np.testing.assert_array_equal(z["stiffness"], U[3][:, 2:])
+    np.testing.assert_allclose(z["t"], np.arange(40) * 1e-2)
+    assert np.load(solver.export_solution(str(tmp_path / "all.npz"), trajectory=None))["q"].shape == (8, 41, 2)
+
+
+def test_verbose_table_of_a_single_problem_and_logger_grads(oracle):
+    """B = 1: Crocoddyl's verbose table (header every 10 iterations; iter, cost, stop, grad = -d[1], xreg, ureg, step,
+    feas) and CallbackLogger.grads = -expectedImprovement()[1], row by row against the oracle's log."""
+    import io
+    sc = scenarios.two_dof_sea(B=1, T=30)
+    problem = crocoddyl.ShootingProblem(sc["x0"][0], sc["running"], sc["terminal"])
+    solver = crocoddyl.SolverFDDP(problem)
+    solver.th_stop = sc["th_stop"]
+    out, log = io.StringIO(), crocoddyl.CallbackLogger()
+    solver.setCallbacks([log, crocoddyl.CallbackVerbose(out)])
+    solver.solve([], [], 25)
+    ref = oracle.solve(problem.lowered, scenarios.solver_params(sc, solver="SolverFDDP", maxiter=25), log_cap=25)
+    n = int(ref["traj_i"][_abi.TI_ITER][0])
+    assert log.iters == list(range(n))
+    np.testing.assert_allclose(log.grads, -ref["log"][:n, _abi.LOG_D2, 0], rtol=1e-6, atol=1e-14)
+    np.testing.assert_allclose(log.costs, ref["log"][:n, _abi.LOG_COST, 0], rtol=1e-9)
+    lines = out.getvalue().splitlines()
+    headers = [i for i, l in enumerate(lines) if l.startswith("iter")]
+    assert headers == [11 * k for k in range((n + 9) // 10)]
+    rows = [l.split() for l in lines if not l.startswith("iter")]
+    assert len(rows) == n and [int(r[0]) for r in rows] == list(range(n))
+    for r, k in zip(rows, range(n)):
+        assert float(r[1]) == pytest.approx(ref["log"][k, _abi.LOG_COST, 0], rel=2e-5)
+        assert float(r[6]) == pytest.approx(ref["log"][k, _abi.LOG_STEP, 0], abs=1e-4)
+        assert int(r[7]) == int(ref["log"][k, _abi.LOG_FEASIBLE, 0])
+
+
+def test_rollout_leaves_a_solve_in_progress_untouched():
+    """ShootingProblem.rollout() uses the forward kernel with zero gains: the gains, the candidate and the feasibility
+    flags it overwrites are put back."""
+    import torch
+    sc = scenarios.two_dof_sea(B=1, T=15)
+    problem = crocoddyl.ShootingProblem(sc["x0"][0], sc["running"], sc["terminal"])
+    solver = crocoddyl.SolverDDP(problem)
+    solver.solve([], [], 4)
+    e = problem.engine
+    before = {r: e.region(r).clone() for r in (_abi.R_XS, _abi.R_US, _abi.R_KGAIN, _abi.R_KFF)}
+    feas = e.traj_i(_abi.TI_FEASIBLE).clone()
+    xs = problem.rollout([np.array([0.01, 0.02])] * 15)
+    assert len(xs) == 16
+    for r, t in before.items():
+        assert torch.equal(e.region(r), t)
+    assert torch.equal(e.traj_i(_abi.TI_FEASIBLE), feas)
+
+
+def test_engine_runs_on_its_own_device_whatever_the_current_one():
+    """Every ABI call is made with the engine's device current (the library launches on the calling thread's device)."""
+    import torch
+    from aslr_to_amd.engine import Engine
+    sc = scenarios.two_dof_sea(B=4, T=5)
+    e = Engine(scenarios.lower(sc), "cuda:0")
+    assert e.device == torch.device("cuda", 0)
+    e.set_candidate(None, None)
+    e.calc_diff()
+    torch.cuda.synchronize()
+    assert torch.isfinite(e.region(_abi.R_COST)).all()

@@ -29,3 +29,21 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     c = d["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] == "port" and c["value"] > 0
     assert abs(d["value"] - 256 * 100 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+
+
+def test_bench_gpus_2_launches_its_own_two_ranks():
+    """`--gpus 2` without a torch.distributed.run wrapper: bench.py starts the two ranks itself.  On this one-GPU box
+    the rehearsal switch puts both on cuda:0 with gloo for the two reductions (the throughput is then meaningless;
+    the launch, the sharding, the barriers and the max-over-ranks timing are what is exercised)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["ASLR_BENCH_REHEARSAL"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                          "--batch-per-gpu", "256"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["ranks"]["launcher"] == "bench.py"
+    assert d["config"]["global_batch"] == 512 and d["solver_state"]["n"] == 512
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    assert abs(d["value"] - 512 * 100 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6

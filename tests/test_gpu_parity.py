@@ -294,12 +294,11 @@ def test_large_shard_kernel_variants_match_oracle(oracle, name, solver):
     e.set_candidate(None, None)
     e.solve(sp, poll_every=0)
     _sync()
-    # (the "a line-search trial overflowed" note is left out of the comparison: whether a run-away trial -- rejected
-    #  either way -- crosses 1e30 within the horizon depends on the last bits of the dynamics; here it differs for
-    #  one trajectory of 2051 whose accepted iterates agree to 1e-10)
-    keep = ~np.int32(_abi.ST_FORWARD_ERR)
+    # full status words, "a line-search trial overflowed" (ST_FORWARD_ERR) included: the rollouts test |xnext|_inf like
+    # Crocoddyl's raiseIfNaN (round 1 tested the 1-norm, which flagged a run-away trial whose inf-norm was still
+    # below 1e30 -- one trajectory of these 2051)
     np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER])
-    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)) & keep, ref["traj_i"][_abi.TI_STATUS] & keep)
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)), ref["traj_i"][_abi.TI_STATUS])
     scale = np.maximum(1.0, np.abs(ref["xs"]).max(axis=(0, 2)))
     assert (np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max(axis=(0, 2)) < 1e-6 * scale).all()
     uscale = np.maximum(1.0, np.abs(ref["us"]).max(axis=(0, 2)))
@@ -313,7 +312,7 @@ def test_large_shard_kernel_variants_match_oracle(oracle, name, solver):
     e.set_candidate(None, None)
     e.solve(sp, poll_every=0)
     _sync()
-    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)) & keep, ref["traj_i"][_abi.TI_STATUS] & keep)
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)), ref["traj_i"][_abi.TI_STATUS])
     scale = np.maximum(1.0, np.abs(ref["xs"]).max(axis=(0, 2)))
     assert (np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max(axis=(0, 2)) < 1e-6 * scale).all()
 
