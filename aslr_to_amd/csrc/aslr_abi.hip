@@ -152,6 +152,7 @@ void fill_planar(const aslr_chain_t &c, PlanarChain *pl) {
     if (!(R[0] == R[4] && R[1] == -R[3])) return;
     pl->cphi[i] = R[0];
     pl->sphi[i] = R[3];
+    pl->phi[i] = std::atan2(R[3], R[0]);
     pl->px[i] = c.joint_p[i][0];
     pl->py[i] = c.joint_p[i][1];
     z += c.joint_p[i][2];
@@ -177,6 +178,40 @@ void fill_planar(const aslr_chain_t &c, PlanarChain *pl) {
     pl->two[7] = pl->m[1] * pl->cx[1];
   }
   pl->ok = 1;
+}
+
+// rotation about z (exact pattern test, as for the joint placements); *c, *s its cos / sin
+bool z_rotation(const double *R, double *c, double *s) {
+  if (!(R[2] == 0.0 && R[5] == 0.0 && R[6] == 0.0 && R[7] == 0.0 && R[8] == 1.0)) return false;
+  if (!(R[0] == R[4] && R[1] == -R[3])) return false;
+  *c = R[0]; *s = R[3];
+  return true;
+}
+bool is_identity3(const double *R) {
+  for (int i = 0; i < 9; ++i) if (R[i] != (i % 4 == 0 ? 1.0 : 0.0)) return false;
+  return true;
+}
+
+// Closed-form frame-placement residuals (ChainPlanar::reach_residual) need: a planar chain, every cost frame turned
+// about z on its joint, every reference rotation -- cost defaults and per-trajectory overrides -- exactly the identity.
+// ASLR_NO_PLANAR_REACH=1 keeps the general SE(3) log.
+void fill_planar_reach(const aslr_problem_desc_t *d, DevDesc *hd) {
+  hd->planar.reach_ok = 0;
+  for (int i = 0; i < d->nmodels; ++i)
+    for (int c = 0; c < ASLR_MAX_COSTS; ++c) { hd->models[i].fr_c[c] = 1.0; hd->models[i].fr_s[c] = 0.0; hd->models[i].fr_phi[c] = 0.0; }
+  const char *e = getenv("ASLR_NO_PLANAR_REACH");
+  if (!hd->planar.ok || (e && atoi(e))) return;
+  for (int i = 0; i < d->nmodels; ++i)
+    for (int c = 0; c < d->models[i].ncosts; ++c) {
+      const aslr_cost_t &ct = d->models[i].costs[c];
+      if (ct.type != ASLR_COST_FRAME_PLACEMENT) continue;
+      double cc, ss;
+      if (!z_rotation(ct.frame_R, &cc, &ss) || !is_identity3(ct.ref)) return;
+      hd->models[i].fr_c[c] = cc; hd->models[i].fr_s[c] = ss; hd->models[i].fr_phi[c] = std::atan2(ss, cc);
+    }
+  if (d->frame_ref)
+    for (int b = 0; b < d->B; ++b) if (!is_identity3(d->frame_ref + 12 * (size_t)b)) return;
+  hd->planar.reach_ok = 1;
 }
 
 SolverDev to_dev(const aslr_solver_params_t *sp, int standalone, int store_v) {
@@ -332,6 +367,8 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   hd->chain = desc->chain;
   fill_planar(desc->chain, &hd->planar);
   const int planar_ok = hd->planar.ok;
+  fill_planar_reach(desc, hd);
+  const int planar_reach = hd->planar.reach_ok;
   for (int i = 0; i < desc->nmodels; ++i) {
     hd->models[i].m = desc->models[i];
     if (!invert(nj, desc->models[i].B, hd->models[i].Binv)) {
@@ -374,6 +411,7 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   k.traj_f = (double *)reg(ASLR_R_TRAJ_F); k.traj_i = (int32_t *)reg(ASLR_R_TRAJ_I);
   k.B = desc->B; k.T = desc->T;
   k.planar = planar_ok;
+  k.planar_reach = planar_reach;
   k.iter_log = nullptr; k.log_cap = 0;
   *out = p;
   return ASLR_OK;

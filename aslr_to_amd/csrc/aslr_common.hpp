@@ -39,6 +39,7 @@ struct KArgs {
   int32_t *traj_i;
   int32_t B, T;
   int32_t planar; // the chain qualifies for the planar dynamics path (DevDesc::planar.ok)
+  int32_t planar_reach; // ... and the frame-placement costs for the closed-form residual (DevDesc::planar.reach_ok)
   double *iter_log;  // per-iteration log [log_cap][ASLR_LOG_COUNT][B] (aslr_set_iteration_log), or nullptr
   int32_t log_cap;
 };

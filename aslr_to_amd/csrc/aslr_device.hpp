@@ -138,11 +138,18 @@ ASLR_DEV void sincos_fast(const SinCosK &K, double x, double *sn, double *cs) {
 struct DevModel {
   aslr_model_t m;
   double Binv[ASLR_MAX_NJ * ASLR_MAX_NJ];
+  // frame-placement costs whose frame is turned about z on its joint (planar fast path, PlanarChain::reach_ok):
+  // cos, sin and angle of that rotation, per cost term; filled on the host
+  double fr_c[ASLR_MAX_COSTS], fr_s[ASLR_MAX_COSTS], fr_phi[ASLR_MAX_COSTS];
 };
 // Planar restatement of the chain (valid when `ok`): every joint axis is +z and every joint
 // placement rotates about z.  Filled on the host at problem creation.
 struct PlanarChain {
-  int32_t ok, _pad;
+  int32_t ok;
+  // the frame-placement residuals take the closed form of ChainPlanar::reach_residual: every cost frame is turned
+  // about z on its joint and every reference rotation (cost defaults and per-trajectory overrides) is the identity
+  int32_t reach_ok;
+  double phi[ASLR_MAX_NJ]; // angle of the joint placement rotation (atan2(sphi, cphi))
   double gx, gy;
   double cphi[ASLR_MAX_NJ], sphi[ASLR_MAX_NJ], px[ASLR_MAX_NJ], py[ASLR_MAX_NJ], pz[ASLR_MAX_NJ];
   double m[ASLR_MAX_NJ], cx[ASLR_MAX_NJ], cy[ASLR_MAX_NJ], izz[ASLR_MAX_NJ];
@@ -602,6 +609,9 @@ struct Chain3D {
     }
     return r;
   }
+  // (planar chains only: ChainPlanar::reach_residual)
+  ASLR_DEV static void reach_residual(const Consts &, const double *, int, const double *, double, double, double,
+                                      const double *, double (&)[6]) {}
   // LOCAL frame Jacobian column j: (oMf^-1 oMj).act(S_j)
   ASLR_DEV SV jac_col(int j, const SE3d &oMf) const {
     SE3d fMj;
@@ -641,13 +651,14 @@ struct ChainPlanar {
   // chain constants copied once into registers (uniform values end up in SGPRs), so a kernel that
   // evaluates many knots per lane does not re-fetch them every knot
   struct Consts {
-    double gx, gy, cphi[NJ], sphi[NJ], px[NJ], py[NJ], pz[NJ], m[NJ], cx[NJ], cy[NJ], izz[NJ];
+    double gx, gy, cphi[NJ], sphi[NJ], px[NJ], py[NJ], pz[NJ], m[NJ], cx[NJ], cy[NJ], izz[NJ], phi[NJ];
     double two[8];
     SinCosK sck;
     ASLR_DEV explicit Consts(const DevDesc &D, bool loop_kernel = false) : sck(loop_kernel) {
       const PlanarChain &p = D.planar;
       gx = p.gx; gy = p.gy;
       ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+        phi[i] = p.phi[i];
         cphi[i] = p.cphi[i]; sphi[i] = p.sphi[i]; px[i] = p.px[i]; py[i] = p.py[i]; pz[i] = p.pz[i];
         m[i] = p.m[i]; cx[i] = p.cx[i]; cy[i] = p.cy[i]; izz[i] = p.izz[i];
       }
@@ -798,6 +809,41 @@ struct ChainPlanar {
     ChainPlanar ch(cc);
     ch.setup(q);
     return ch.joint_world(fj);
+  }
+  // Frame-placement residual r = log6(Mref^-1 oMf).vector (residual_frame_placement.py:13-15) in closed form, for a
+  // frame on joint fj turned about z by phiF (cF, sF = its cos, sin; Fp its offset) and a reference placement with
+  // identity rotation at pref: the relative rotation is Rz(psi) with psi = sum_{i <= fj} (phi_i + q_i) + phiF wrapped
+  // to (-pi, pi], so the angular part is w = (0, 0, psi) and, with p = oMf.p - pref and t = |psi|,
+  //   r = [alpha p_x + psi p_y / 2, alpha p_y - psi p_x / 2, p_z, 0, 0, psi],   alpha = t sin t / (2 (1 - cos t)):
+  // log6()'s formulas with w x p = psi (-p_y, p_x, 0); on the z component alpha + beta t^2 = 1.  No acos, no 3-D
+  // products, one division -- a cost-only evaluation is otherwise dominated by the general SE(3) log.
+  ASLR_DEV static void reach_residual(const Consts &cc, const double *q, int fj, const double *Fp, double cF, double sF,
+                                      double phiF, const double *pref, double (&r)[6]) {
+    double th = 0.0, Px = 0.0, Py = 0.0, Pz = 0.0, c = 1.0, s = 0.0; // world angle / origin of the frame reached so far
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+      if (i <= fj) { // wave-uniform (fj is a constant of the cost)
+        Px += c * cc.px[i] - s * cc.py[i];
+        Py += s * cc.px[i] + c * cc.py[i];
+        Pz = cc.pz[i];
+        th += cc.phi[i] + q[i];
+        sincos_fast(cc.sck, th, &s, &c);
+      }
+    }
+    const double px_ = (Px + (c * Fp[0] - s * Fp[1])) - pref[0];
+    const double py_ = (Py + (s * Fp[0] + c * Fp[1])) - pref[1];
+    const double pz_ = (Pz + Fp[2]) - pref[2];
+    // psi in (-pi, pi]: two-term reduction by 2 pi
+    double psi = th + phiF;
+    const double kk = rint(psi * 1.59154943091895335769e-01);
+    psi = fma(-kk, 6.28318530717958623200e+00, psi) - kk * 2.44929359829470635445e-16;
+    const double cr = c * cF - s * sF, sr = s * cF + c * sF; // (cF = 1, sF = 0 leave c, s unchanged, bit for bit)
+    const double t = fabs(psi), st = fabs(sr), ct = cr;
+    const double t2 = t * t;
+    const double alpha = t < kTaylorPrec ? 1.0 - t2 / 12.0 - t2 * t2 / 720.0 : t * st / (2.0 * (1.0 - ct));
+    r[0] = alpha * px_ + 0.5 * psi * py_;
+    r[1] = alpha * py_ - 0.5 * psi * px_;
+    r[2] = pz_;
+    r[3] = 0.0; r[4] = 0.0; r[5] = psi;
   }
   ASLR_DEV SV jac_col(int j, const SE3d &oMf) const {
     // joint j turns the frame about the world z axis through (Px[j], Py[j])
@@ -1014,6 +1060,8 @@ constexpr int kEvalPre = 8;  // the rigid-body part (xout, M^-1, dtau/dq, dtau/d
 constexpr int kEvalSkipCost = 16; // with kEvalDiff: dynamics and its derivatives only (first half of a split evaluation)
 constexpr int kEvalSkipDyn = 32;  // with kEvalDiff: cost stack and its derivatives only (second half)
 constexpr int kEvalResid = 64;    // also store the stacked cost residuals (data.r) through `resid`
+constexpr int kEvalFastReach = 128; // cost-only evaluations on a planar chain with PlanarChain::reach_ok: frame-placement
+                                    // residuals in closed form (ChainPlanar::reach_residual)
 
 // calc (+ calcDiff): x[4NJ], u[NU] -> xnext, cost (+ compact derivatives).
 // u == nullptr selects the model's "u is None" default (terminal node).
@@ -1026,6 +1074,7 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
                         double *xout_o = nullptr, const double *pre = nullptr, double *resid = nullptr) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
   constexpr bool RESID = (WHAT & kEvalResid) != 0;
+  constexpr bool FASTREACH = (WHAT & kEvalFastReach) != 0 && (WHAT & kEvalDiff) == 0;
   int roff = 0; // running offset into `resid`
   constexpr bool DIFF = (WHAT & kEvalDiff) != 0;
   constexpr bool DYN = (DIFF || (WHAT & kEvalDyn) != 0) && (WHAT & kEvalSkipDyn) == 0;
@@ -1150,7 +1199,17 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
   for (int ci = 0; ci < m.ncosts; ++ci) {
     const aslr_cost_t &ct = m.costs[ci];
     const double w = ct.weight;
-    if (ct.type == ASLR_COST_FRAME_PLACEMENT) {
+    if (FASTREACH && ct.type == ASLR_COST_FRAME_PLACEMENT) {
+      if constexpr (FASTREACH) {
+        const double *ref = frame_ref ? frame_ref : ct.ref;
+        double r[6];
+        CH::reach_residual(cc, q, ct.frame_joint, ct.frame_p, dm.fr_c[ci], dm.fr_s[ci], dm.fr_phi[ci], ref + 9, r);
+        double a = 0.0;
+        ASLR_UNROLL for (int i = 0; i < 6; ++i) a += ct.act_w[i] * r[i] * r[i];
+        cost += w * 0.5 * a;
+        if constexpr (RESID) { ASLR_UNROLL for (int i = 0; i < 6; ++i) resid[roff + i] = r[i]; roff += 6; }
+      }
+    } else if (ct.type == ASLR_COST_FRAME_PLACEMENT) {
       const int fj = ct.frame_joint;
       SE3d oMj;
       if constexpr (WORLDONLY) oMj = ch.joint_world_ready(fj);

@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
 }
 
 // cost of every stored candidate knot: COST_TRY[a][t][b]
-template <int NJ, int DAM, bool PLANAR>
+// FAST (planar chains with PlanarChain::reach_ok): closed-form frame-placement residual
+template <int NJ, int DAM, bool PLANAR, bool FAST = false>
 __global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
   using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
   const typename CH::Consts cc(D);
   ModelRegs<NJ, NU> mr;
   mr.load(dm);
-  knot_eval<NJ, DAM, kEvalCost, CH>(cc, mr, dm, fref, x, t < T ? u : nullptr, xnext, c, nullptr);
+  knot_eval<NJ, DAM, kEvalCost | (FAST && PLANAR ? kEvalFastReach : 0), CH>(cc, mr, dm, fref, x, t < T ? u : nullptr, xnext, c, nullptr);
   a.cost_try[(size_t)ai * TB1 + tb] = c;
 }
 

@@ -9,7 +9,8 @@ int launch_forward_nj2(const KArgs &k, int dam, const SolverDev &sd, const Model
     if (k.planar) {
       if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_SEA, true, true>), grid, block, 0, st, k, sd, lim);
       else hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_SEA, true, false>), grid, block, 0, st, k, sd, lim);
-      hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_SEA, true>), cgrid, cblock, 0, st, k, sd);
+      if (k.planar_reach) hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_SEA, true, true>), cgrid, cblock, 0, st, k, sd);
+      else hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_SEA, true>), cgrid, cblock, 0, st, k, sd);
     } else {
       if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_SEA, false, true>), grid, block, 0, st, k, sd, lim);
       else hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_SEA, false, false>), grid, block, 0, st, k, sd, lim);
@@ -24,7 +25,8 @@ int launch_forward_nj2(const KArgs &k, int dam, const SolverDev &sd, const Model
     if (k.planar) {
       if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, true, true>), grid, block, 0, st, k, sd, lim);
       else hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, true, false>), grid, block, 0, st, k, sd, lim);
-      hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_VSA, true>), cgrid, cblock, 0, st, k, sd);
+      if (k.planar_reach) hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_VSA, true, true>), cgrid, cblock, 0, st, k, sd);
+      else hipLaunchKernelGGL((trial_cost_kernel<2, ASLR_DAM_VSA, true>), cgrid, cblock, 0, st, k, sd);
     } else {
       if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, false, true>), grid, block, 0, st, k, sd, lim);
       else hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_VSA, false, false>), grid, block, 0, st, k, sd, lim);
