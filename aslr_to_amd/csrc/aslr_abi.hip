@@ -194,13 +194,17 @@ bool is_identity3(const double *R) {
 
 // Closed-form frame-placement residuals (ChainPlanar::reach_residual) need: a planar chain, every cost frame turned
 // about z on its joint, every reference rotation -- cost defaults and per-trajectory overrides -- exactly the identity.
-// ASLR_NO_PLANAR_REACH=1 keeps the general SE(3) log.
+// OFF unless ASLR_PLANAR_REACH=1: the closed form agrees with the general SE(3) log to 1e-12 relative, but the last
+// iterations of a converging solve compare trial costs that differ by 1e-12 relative (dV ~ 1e-10 on a cost of ~300),
+// so a differently ROUNDED cost flips one of those line-search decisions in 12 % of the trajectories of the headline
+// batch (512 of 4096 against 6 with the general path, profiles/r02/parity_headline_4096_planar_reach.txt), for 8 us
+// per iteration: the trial-cost kernel is bound by reading the 396 MB of candidates, not by the log map.
 void fill_planar_reach(const aslr_problem_desc_t *d, DevDesc *hd) {
   hd->planar.reach_ok = 0;
   for (int i = 0; i < d->nmodels; ++i)
     for (int c = 0; c < ASLR_MAX_COSTS; ++c) { hd->models[i].fr_c[c] = 1.0; hd->models[i].fr_s[c] = 0.0; hd->models[i].fr_phi[c] = 0.0; }
-  const char *e = getenv("ASLR_NO_PLANAR_REACH");
-  if (!hd->planar.ok || (e && atoi(e))) return;
+  const char *e = getenv("ASLR_PLANAR_REACH");
+  if (!hd->planar.ok || !(e && atoi(e))) return;
   for (int i = 0; i < d->nmodels; ++i)
     for (int c = 0; c < d->models[i].ncosts; ++c) {
       const aslr_cost_t &ct = d->models[i].costs[c];
@@ -224,7 +228,7 @@ SolverDev to_dev(const aslr_solver_params_t *sp, int standalone, int store_v) {
   s.reg_decfactor = sp->reg_decfactor;
   s.boxqp_maxiter = sp->boxqp_maxiter; s.boxqp_th_acceptstep = sp->boxqp_th_acceptstep;
   s.boxqp_th_grad = sp->boxqp_th_grad; s.boxqp_reg = sp->boxqp_reg;
-  s.standalone = standalone; s.store_v = store_v;
+  s.standalone = standalone; s.store_v = store_v; s.wave_filter = 0;
   return s;
 }
 

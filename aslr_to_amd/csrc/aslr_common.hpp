@@ -68,6 +68,10 @@ struct SolverDev {
   double boxqp_th_acceptstep, boxqp_th_grad, boxqp_reg;
   int32_t standalone; // 1: API-level single pass (no retry, no solver-state updates)
   int32_t store_v;    // 1: write VX / VXX
+  // backward sweep launched as a pair (DDP / BoxDDP solves): 1 = first launch, gap-aware body: does the per-trajectory
+  // bookkeeping of every wave, then sweeps only the waves that hold an infeasible trajectory; 2 = second launch, lean
+  // body: no bookkeeping, sweeps the waves whose live trajectories are all feasible; 0 = single launch
+  int32_t wave_filter;
 };
 
 // control limits of the (at most ASLR_MAX_MODELS) action models, passed by value so the backward loop

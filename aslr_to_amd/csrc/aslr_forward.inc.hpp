@@ -13,6 +13,11 @@
 #pragma once
 #include "aslr_common.hpp"
 
+#ifndef ASLR_ROLLOUT_TPW
+#define ASLR_ROLLOUT_TPW 4 // trajectories (16-lane teams) per rollout wave: 4 fills the wave; 2 leaves half of it idle but puts
+                           // two waves on every SIMD at 4096 trajectories, which hide each other's latency
+#endif
+
 namespace aslr {
 
 // FDDP: the gap-contracting rollout and the dv terms of SolverFDDP are compiled in (two more 8-double prefetch
@@ -20,12 +25,12 @@ namespace aslr {
 template <int NJ, int DAM, bool PLANAR, bool FDDP>
 __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
-  constexpr int TEAM = 16, TPW = 4;
+  constexpr int TEAM = 16, TPW = ASLR_ROLLOUT_TPW;
   using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
   const int lane = threadIdx.x, team = lane / TEAM, al = lane % TEAM;
   const int B = a.B, T = a.T;
   const int bq = blockIdx.x * TPW + team;
-  const bool team_valid = bq < B;
+  const bool team_valid = team < TPW && bq < B;
   const int b = team_valid ? bq : B - 1;
   int32_t *TI = a.traj_i;
   double *TF = a.traj_f;

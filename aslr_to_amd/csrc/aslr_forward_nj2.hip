@@ -3,7 +3,7 @@
 
 namespace aslr {
 int launch_forward_nj2(const KArgs &k, int dam, const SolverDev &sd, const ModelLimits &lim, hipStream_t st) {
-  dim3 grid((k.B + 3) / 4), block(64), cgrid((k.B + 63) / 64, k.T + 1, ASLR_NALPHA), sgrid((k.B + 63) / 64),
+  dim3 grid((k.B + ASLR_ROLLOUT_TPW - 1) / ASLR_ROLLOUT_TPW), block(64), cgrid((k.B + 63) / 64, k.T + 1, ASLR_NALPHA), sgrid((k.B + 63) / 64),
       cblock(64), ugrid((k.B + 63) / 64, ASLR_NALPHA);
   if (dam == ASLR_DAM_SEA) {
     if (k.planar) {

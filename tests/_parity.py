@@ -38,6 +38,19 @@ def first_decision_flip(lg, lr, b):
     return None
 
 
+def first_cost_drift(lg, lr, b, rel=1e-9):
+    """First iteration at which the logged costs of both sides differ by more than `rel` (relative): where a difference
+    that is not a logged decision -- a BoxQP active set, an ill-conditioned step -- first shows.  -> (k, cost_g, cost_r) or None"""
+    n = min(lg.shape[0], lr.shape[0])
+    for k in range(n):
+        a, c = lg[k, A.LOG_COST, b], lr[k, A.LOG_COST, b]
+        if np.isnan(a) or np.isnan(c):
+            return None
+        if abs(a - c) > rel * max(1.0, abs(c)):
+            return k, float(a), float(c)
+    return None
+
+
 def compare(gpu, ref, sp):
     """gpu / ref: dict(xs [T+1,B,nx], us, traj_f, traj_i, log).  -> dict of per-trajectory arrays and the list of
     exceptions (trajectories whose iteration count, status, or converged iterates beyond 1e-6 / 1e-4 differ)."""
@@ -53,7 +66,8 @@ def compare(gpu, ref, sp):
     rows = []
     for b in np.nonzero(odd)[0]:
         flip = first_decision_flip(gpu["log"], ref["log"], int(b))
-        rows.append(dict(b=int(b), it_gpu=int(it_g[b]), it_oracle=int(it_r[b]), st_gpu=int(st_g[b]), st_oracle=int(st_r[b]),
+        drift = first_cost_drift(gpu["log"], ref["log"], int(b))
+        rows.append(dict(b=int(b), drift=drift, it_gpu=int(it_g[b]), it_oracle=int(it_r[b]), st_gpu=int(st_g[b]), st_oracle=int(st_r[b]),
                          dx=float(dx[b]), du=float(du[b]), dcost=float(dc[b]),
                          stop_gpu=float(gpu["traj_f"][A.TF_STOP][b]), stop_oracle=float(ref["traj_f"][A.TF_STOP][b]),
                          flip=flip))
@@ -71,6 +85,10 @@ def describe(row, sp):
     head = ("traj %4d: iterations gpu %3d / oracle %3d, status %2d / %2d, |dx| %.2e |du| %.2e |dcost| %.2e, "
             "final stop %.3e / %.3e" % (row["b"], row["it_gpu"], row["it_oracle"], row["st_gpu"], row["st_oracle"],
                                         row["dx"], row["du"], row["dcost"], row["stop_gpu"], row["stop_oracle"]))
+    d = row.get("drift")
+    if d is not None and (f is None or d[0] < f["iteration"]):
+        head += (" | costs part ways (> 1e-9 relative) at iteration %d: %.12e / %.12e, with the same logged decisions "
+                 "up to there (a BoxQP active set or an ill-conditioned step)" % d)
     if f is None:
         return head + " | same decisions at every iteration (rounding drift only)"
     g, r, k = f["gpu"], f["oracle"], f["iteration"]
