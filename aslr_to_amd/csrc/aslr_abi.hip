@@ -261,7 +261,19 @@ int backward_hs(const aslr_problem *p) {
   return e ? atoi(e) : 0;
 }
 
+// nj = 7 with VSA actuation (nx = 28, nu = 14) is built at the MODEL level only -- calc / calcDiff sweeps, dam_eval,
+// dam_residuals, frame placements: what the reference exercises for that combination
+// (unittest/test_free_placementcost_free_fwddyn.py:12-46) -- not in the solver kernels
+int solver_unsupported(const aslr_problem *p) {
+  if (p->nj == 7 && p->dam == ASLR_DAM_VSA) {
+    snprintf(g_err, sizeof g_err, "the solver kernels are not built for (nj=7, VSA): model-level evaluation only");
+    return ASLR_E_INVALID;
+  }
+  return ASLR_OK;
+}
+
 int launch_backward(aslr_problem *p, const SolverDev &sd, hipStream_t st, bool all_feasible = false) {
+  if (int rc = solver_unsupported(p)) return rc;
   const int hs = backward_hs(p);
   const ModelLimits lim = make_limits(p);
   if (p->nx == 8) return launch_backward_nx8(p->k, p->nu, hs, sd, lim, all_feasible, st);
@@ -271,6 +283,7 @@ int launch_backward(aslr_problem *p, const SolverDev &sd, hipStream_t st, bool a
 }
 
 int launch_forward(aslr_problem *p, const SolverDev &sd, hipStream_t st) {
+  if (int rc = solver_unsupported(p)) return rc;
   const ModelLimits lim = make_limits(p);
   if (p->nj == 2) return launch_forward_nj2(p->k, p->dam, sd, lim, st);
   if (p->nj == 7) return launch_forward_nj7(p->k, p->dam, sd, lim, st);
@@ -338,8 +351,8 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   if (!desc->node_model || !desc->x0) return ASLR_E_INVALID;
   for (int t = 0; t <= desc->T; ++t)
     if (desc->node_model[t] < 0 || desc->node_model[t] >= desc->nmodels) return ASLR_E_INVALID;
-  if (!((nj == 2) || (nj == 7 && dam == ASLR_DAM_SEA))) {
-    snprintf(g_err, sizeof g_err, "unsupported (nj=%d, dam=%d): built for nj=2 SEA/VSA, nj=7 SEA", nj, dam);
+  if (!(nj == 2 || nj == 7)) {
+    snprintf(g_err, sizeof g_err, "unsupported nj=%d: built for nj=2 and nj=7 (SEA / VSA)", nj);
     return ASLR_E_INVALID;
   }
   int ndev = 0;
@@ -457,6 +470,7 @@ int aslr_forward_pass(aslr_problem_t *p, const aslr_solver_params_t *sp, void *s
 
 int aslr_iterate(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream) {
   if (!p || !sp) return ASLR_E_INVALID;
+  if (int rc = solver_unsupported(p)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (first) {
     const double reg0 = std::isnan(sp->reg_init) ? sp->reg_min : sp->reg_init;
@@ -473,6 +487,7 @@ int aslr_iterate(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t firs
 
 int aslr_iterate_timed(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream, float *ms3) {
   if (!p || !sp || !ms3) return ASLR_E_INVALID;
+  if (int rc = solver_unsupported(p)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!p->have_ev) {
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&p->ev[i]));
@@ -606,6 +621,7 @@ int aslr_quasi_static(aslr_problem_t *p, int32_t maxiter, double tol, int32_t *i
   if (!p || maxiter <= 0) return ASLR_E_INVALID;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (p->nj == 2) return launch_quasi_static_nj2(p->k, p->dam, maxiter, tol, iters_dev, st);
+  if (int rc = solver_unsupported(p)) return rc;
   if (p->nj == 7) return launch_quasi_static_nj7(p->k, p->dam, maxiter, tol, iters_dev, st);
   snprintf(g_err, sizeof g_err, "unsupported nj=%d", p->nj);
   return ASLR_E_INVALID;

@@ -19,6 +19,12 @@ int launch_calc_nj7(const KArgs &k, int dam, bool diff, int mode, double th_gapt
     HIP_TRY(hipGetLastError());
     return ASLR_OK;
   }
+  if (dam == ASLR_DAM_VSA) { // model-level support (ShootingProblem.calc / calcDiff): the per-lane kernel
+    if (diff) hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_VSA, true, false>), grid, block, 0, st, k, mode, th_gaptol);
+    else hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_VSA, false, false>), grid, block, 0, st, k, mode, th_gaptol);
+    HIP_TRY(hipGetLastError());
+    return ASLR_OK;
+  }
   snprintf(err_buf(), kErrLen, "calc: unsupported (nj=7, dam=%d)", dam);
   return ASLR_E_INVALID;
 }
@@ -32,6 +38,11 @@ int launch_dam_eval_nj7(const KArgs &k, int dam, int mi, int n, const double *x,
     HIP_TRY(hipGetLastError());
     return ASLR_OK;
   }
+  if (dam == ASLR_DAM_VSA) {
+    hipLaunchKernelGGL((dam_eval_kernel<7, ASLR_DAM_VSA, false>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, xout, cost, Fx, Fu, Lx, Lu, Lxx, Lxu, Luu);
+    HIP_TRY(hipGetLastError());
+    return ASLR_OK;
+  }
   snprintf(err_buf(), kErrLen, "dam_eval: unsupported (nj=7, dam=%d)", dam);
   return ASLR_E_INVALID;
 }
@@ -40,6 +51,11 @@ int launch_dam_residuals_nj7(const KArgs &k, int dam, int mi, int n, const doubl
   dim3 grid((n + 63) / 64), block(64);
   if (dam == ASLR_DAM_SEA) {
     hipLaunchKernelGGL((dam_residual_kernel<7, ASLR_DAM_SEA, false>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, r, nr);
+    HIP_TRY(hipGetLastError());
+    return ASLR_OK;
+  }
+  if (dam == ASLR_DAM_VSA) {
+    hipLaunchKernelGGL((dam_residual_kernel<7, ASLR_DAM_VSA, false>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, r, nr);
     HIP_TRY(hipGetLastError());
     return ASLR_OK;
   }

@@ -150,6 +150,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # stdout carries the ONE JSON line and nothing else: whatever the libraries below print there (gloo's connection
+    # notes, ROCm warnings) goes to stderr instead; the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from aslr_to_amd import _abi, dist, scenarios
     from aslr_to_amd.crocoddyl import ShootingProblem
@@ -274,7 +280,8 @@ def main():
             nthreads = os.cpu_count() or 1
         nthreads = min(nthreads, 16)  # the CPU share of a one-GPU box
         out["cpu_baseline"] = cpu_baseline(scenarios.two_dof_vsa_boxddp, nthreads)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -305,12 +305,12 @@ def test_frame_placements_and_residuals_of_node_data_match_the_oracle(oracle):
             for t in (0, problem.T):
                 node = problem.runningDatas.tolist()[t] if t < problem.T else problem.terminalData
                 M = node.differential.multibody.pinocchio.oMf[fid]
+                if fr.parent < 0:   # the universe frame does not move
+                    np.testing.assert_array_equal(M.translation, fr.placement.translation)
+                    continue
                 for b in range(B):
                     R = M.rotation if B == 1 else M.rotation[b].cpu().numpy()
                     p = M.translation if B == 1 else M.translation[b].cpu().numpy()
-                    if fr.parent < 0:
-                        np.testing.assert_array_equal(p, fr.placement.translation)
-                        continue
                     Rr, pr = oracle.frame_placement(chain, xs[b, t, :nj], fr.parent, fr.placement.rotation,
                                                     fr.placement.translation)
                     np.testing.assert_allclose(R, Rr, atol=1e-12)
@@ -386,7 +386,8 @@ def test_batched_logger_matches_the_oracle_iteration_by_iteration(oracle, tmp_pa
     np.testing.assert_allclose(log.grads[on], -rl[:, _abi.LOG_D2][on], rtol=1e-4, atol=1e-12)
     full = solver.iteration_log()
     np.testing.assert_array_equal(full[:, _abi.LOG_ACCEPTED][on], rl[:, _abi.LOG_ACCEPTED][on])
-    np.testing.assert_array_equal(full[:, _abi.LOG_STATUS][on], rl[:, _abi.LOG_STATUS][on])
+    import _parity
+    _parity.assert_status_words_match(full[:, _abi.LOG_STATUS][on], rl[:, _abi.LOG_STATUS][on])
     np.testing.assert_array_equal(full[:, _abi.LOG_FEASIBLE][on], rl[:, _abi.LOG_FEASIBLE][on])
     rows = table.getvalue().splitlines()
     assert rows[0].split()[:2] == ["iter", "active"] and len([r for r in rows if r.split()[0].isdigit()]) == n
