@@ -140,6 +140,7 @@ EXPORTED_SYMBOLS = [
     "aslr_calc", "aslr_calc_diff", "aslr_backward_pass", "aslr_forward_pass", "aslr_solve",
     "aslr_iterate", "aslr_iterate_timed", "aslr_finalize", "aslr_count_active", "aslr_dam_eval", "aslr_quasi_static", "aslr_last_error",
     "aslr_dam_residuals", "aslr_residual_len", "aslr_frame_placement", "aslr_set_iteration_log",
+    "aslr_iterate_n", "aslr_set_subshards",
 ]
 
 
@@ -201,6 +202,10 @@ def load_library():
     lib.aslr_residual_len.argtypes = [C.POINTER(Model), i32]
     lib.aslr_frame_placement.restype = C.c_int
     lib.aslr_frame_placement.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), i32, vp, i64, vp, vp]
+    lib.aslr_iterate_n.restype = C.c_int
+    lib.aslr_iterate_n.argtypes = [vp, C.POINTER(SolverParams), i32, i32, vp]
+    lib.aslr_set_subshards.restype = C.c_int
+    lib.aslr_set_subshards.argtypes = [vp, i32]
     lib.aslr_set_iteration_log.restype = C.c_int
     lib.aslr_set_iteration_log.argtypes = [vp, vp, i32]
     if lib.aslr_abi_version() != ABI_VERSION:

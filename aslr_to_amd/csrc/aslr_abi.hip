@@ -19,8 +19,8 @@ namespace {
 
 // per-trajectory solver state at solve() entry
 __global__ void init_state_kernel(KArgs a, double reg0, int is_feasible) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+  const int b = a.b0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.b1) return;
   const int B = a.B;
   for (int r = 0; r < ASLR_TF_COUNT; ++r) a.traj_f[r * B + b] = 0.0;
   for (int r = 0; r < ASLR_TI_COUNT; ++r) a.traj_i[r * B + b] = 0;
@@ -31,8 +31,8 @@ __global__ void init_state_kernel(KArgs a, double reg0, int is_feasible) {
 }
 
 __global__ void reset_accepted_kernel(KArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < a.B) a.traj_i[ASLR_TI_ACCEPTED * a.B + b] = -1;
+  const int b = a.b0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < a.b1) a.traj_i[ASLR_TI_ACCEPTED * a.B + b] = -1;
 }
 
 } // namespace
@@ -40,6 +40,8 @@ __global__ void reset_accepted_kernel(KArgs a) {
 // =================================================================================================
 // host side: handle, workspace carving, dispatch
 // =================================================================================================
+constexpr int kMaxSub = 4; // HIP maps streams onto 4 hardware queues by default: more sub-shards than that serialise
+
 struct aslr_problem {
   aslr_problem_desc_t desc; // host copy (pointers nulled)
   int nj, nx, nu, dam, rec;
@@ -50,9 +52,17 @@ struct aslr_problem {
   int32_t *h_done; // pinned staging for count_active
   hipEvent_t ev[4];
   bool have_ev;
+  // sub-shards (aslr_set_subshards): contiguous trajectory ranges [sub_b[s], sub_b[s + 1]) iterated on their own
+  // streams, so that the latency-bound sweeps of one overlap the throughput-bound kernels of the others
+  int nsub;
+  int32_t sub_b[kMaxSub + 1];
+  hipStream_t sub_stream[kMaxSub];
+  hipEvent_t sub_fork, sub_join[kMaxSub];
+  bool have_sub;
   // model-only chunks of the DERIV records (cost-weight diagonals): const_ok = the cost stacks allow skipping them,
   // const_written = a sweep that evaluated every knot of every trajectory has put them in place
   bool const_ok, const_written;
+  bool const_pending_full; // aslr_iterate_n: the first sweep of this call is the one that puts them in place
 };
 
 namespace {
@@ -228,7 +238,7 @@ SolverDev to_dev(const aslr_solver_params_t *sp, int standalone, int store_v) {
   s.reg_decfactor = sp->reg_decfactor;
   s.boxqp_maxiter = sp->boxqp_maxiter; s.boxqp_th_acceptstep = sp->boxqp_th_acceptstep;
   s.boxqp_th_grad = sp->boxqp_th_grad; s.boxqp_reg = sp->boxqp_reg;
-  s.standalone = standalone; s.store_v = store_v; s.wave_filter = 0;
+  s.standalone = standalone; s.store_v = store_v;
   return s;
 }
 
@@ -427,6 +437,9 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   k.dyn = (double *)reg(ASLR_R_DYN);
   k.traj_f = (double *)reg(ASLR_R_TRAJ_F); k.traj_i = (int32_t *)reg(ASLR_R_TRAJ_I);
   k.B = desc->B; k.T = desc->T;
+  k.b0 = 0; k.b1 = desc->B;
+  p->nsub = 1; p->have_sub = false;
+  p->sub_b[0] = 0; p->sub_b[1] = desc->B;
   k.planar = planar_ok;
   k.planar_reach = planar_reach;
   k.iter_log = nullptr; k.log_cap = 0;
@@ -438,6 +451,10 @@ int aslr_problem_destroy(aslr_problem_t *p) {
   if (!p) return ASLR_OK;
   if (p->h_done) (void)hipHostFree(p->h_done);
   if (p->have_ev) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(p->ev[i]);
+  if (p->have_sub) {
+    for (int i = 0; i < kMaxSub; ++i) { (void)hipStreamDestroy(p->sub_stream[i]); (void)hipEventDestroy(p->sub_join[i]); }
+    (void)hipEventDestroy(p->sub_fork);
+  }
   delete p;
   return ASLR_OK;
 }
@@ -468,21 +485,89 @@ int aslr_forward_pass(aslr_problem_t *p, const aslr_solver_params_t *sp, void *s
   return launch_forward(p, to_dev(sp, 1, 0), static_cast<hipStream_t>(stream));
 }
 
-int aslr_iterate(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream) {
-  if (!p || !sp) return ASLR_E_INVALID;
-  if (int rc = solver_unsupported(p)) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
+namespace {
+// one lock-step iteration of the trajectories [b0, b1) on stream st
+int iterate_range(aslr_problem *p, const aslr_solver_params_t *sp, int first, int b0, int b1, hipStream_t st) {
+  const KArgs full = p->k;
+  p->k.b0 = b0; p->k.b1 = b1; // (the launch helpers read p->k; restored below)
+  int rc = ASLR_OK;
   if (first) {
     const double reg0 = std::isnan(sp->reg_init) ? sp->reg_min : sp->reg_init;
-    hipLaunchKernelGGL(init_state_kernel, dim3((p->desc.B + 255) / 256), dim3(256), 0, st, p->k, reg0, sp->is_feasible);
-    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(init_state_kernel, dim3((b1 - b0 + 255) / 256), dim3(256), 0, st, p->k, reg0, sp->is_feasible);
+    if (hipGetLastError() != hipSuccess) rc = ASLR_E_HIP;
   }
   const SolverDev sd = to_dev(sp, 0, 0);
-  int rc = launch_calc(p, true, kModeCommit | kModeSolver, sp->th_gaptol, st, first != 0); // the first sweep evaluates all
-  if (rc) return rc;
-  rc = launch_backward(p, sd, st);
-  if (rc) return rc;
-  return launch_forward(p, sd, st);
+  // (the model-only record chunks are marked written by a sweep that covers the WHOLE shard: the last sub-shard's)
+  if (!rc) rc = launch_calc(p, true, kModeCommit | kModeSolver, sp->th_gaptol, st, first != 0 && b1 == p->desc.B && p->const_pending_full);
+  if (!rc) rc = launch_backward(p, sd, st);
+  if (!rc) rc = launch_forward(p, sd, st);
+  p->k = full;
+  return rc;
+}
+
+// fork: the sub-shard streams wait for what the caller's stream has enqueued so far
+int sub_fork(aslr_problem *p, hipStream_t st) {
+  HIP_TRY(hipEventRecord(p->sub_fork, st));
+  for (int s = 0; s < p->nsub; ++s) HIP_TRY(hipStreamWaitEvent(p->sub_stream[s], p->sub_fork, 0));
+  return ASLR_OK;
+}
+// join: the caller's stream waits for every sub-shard stream
+int sub_join(aslr_problem *p, hipStream_t st) {
+  for (int s = 0; s < p->nsub; ++s) {
+    HIP_TRY(hipEventRecord(p->sub_join[s], p->sub_stream[s]));
+    HIP_TRY(hipStreamWaitEvent(st, p->sub_join[s], 0));
+  }
+  return ASLR_OK;
+}
+} // namespace
+
+int aslr_set_subshards(aslr_problem_t *p, int32_t n) {
+  if (!p || n < 1 || n > kMaxSub) return ASLR_E_INVALID;
+  const int B = p->desc.B;
+  // boundaries on multiples of 64 trajectories (a calc block; also whole groups of the interleaved candidate slabs)
+  const int blocks = (B + 63) / 64;
+  if (n > blocks) n = blocks;
+  if (n > 1 && !p->have_sub) {
+    for (int i = 0; i < kMaxSub; ++i) {
+      HIP_TRY(hipStreamCreateWithFlags(&p->sub_stream[i], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&p->sub_join[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&p->sub_fork, hipEventDisableTiming));
+    p->have_sub = true;
+  }
+  p->nsub = n;
+  for (int s = 0; s <= n; ++s) {
+    const long long cut = (long long)blocks * s / n * 64;
+    p->sub_b[s] = (int32_t)(cut > B ? B : cut);
+  }
+  p->sub_b[n] = B;
+  return ASLR_OK;
+}
+
+int aslr_iterate_n(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, int32_t n, void *stream) {
+  if (!p || !sp || n < 0) return ASLR_E_INVALID;
+  if (int rc = solver_unsupported(p)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int B = p->desc.B;
+  p->const_pending_full = !p->const_written;
+  if (p->nsub <= 1) {
+    for (int it = 0; it < n; ++it)
+      if (int rc = iterate_range(p, sp, first && it == 0, 0, B, st)) return rc;
+    return ASLR_OK;
+  }
+  // Each sub-shard runs its n iterations on its own stream with no synchronisation between sub-shards (trajectories
+  // are independent): their kernels interleave freely, the serial sweeps of one under the streaming kernels of the
+  // others.  The caller's stream is forked from before and joined after, so for the caller the call is still "n
+  // iterations enqueued on my stream".
+  if (int rc = sub_fork(p, st)) return rc;
+  for (int it = 0; it < n; ++it)
+    for (int s = 0; s < p->nsub; ++s)
+      if (int rc = iterate_range(p, sp, first && it == 0, p->sub_b[s], p->sub_b[s + 1], p->sub_stream[s])) return rc;
+  return sub_join(p, st);
+}
+
+int aslr_iterate(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream) {
+  return aslr_iterate_n(p, sp, first, 1, stream);
 }
 
 int aslr_iterate_timed(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream, float *ms3) {
@@ -498,7 +583,7 @@ int aslr_iterate_timed(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_
     hipLaunchKernelGGL(init_state_kernel, dim3((p->desc.B + 255) / 256), dim3(256), 0, st, p->k, reg0, sp->is_feasible);
     HIP_TRY(hipGetLastError());
   }
-  const SolverDev sd = to_dev(sp, 0, 0);
+  const SolverDev sd = to_dev(sp, 0, 0); // (whole shard on the caller's stream, whatever aslr_set_subshards says)
   HIP_TRY(hipEventRecord(p->ev[0], st));
   int rc = launch_calc(p, true, kModeCommit | kModeSolver, sp->th_gaptol, st, first != 0); // the first sweep evaluates all
   if (rc) return rc;
@@ -542,15 +627,20 @@ int aslr_solve(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t poll_e
     if (iters_done) *iters_done = 0;
     return ASLR_OK;
   }
+  // iterations are enqueued in chunks of poll_every (all of them when the host never polls): within a chunk the
+  // sub-shard streams run free of each other
   int it = 0;
-  for (; it < sp->maxiter; ++it) {
-    int rc = aslr_iterate(p, sp, it == 0, stream);
+  const bool polling = !sp->fixed_iterations && poll_every > 0;
+  while (it < sp->maxiter) {
+    const int chunk = polling ? (poll_every < sp->maxiter - it ? poll_every : sp->maxiter - it) : sp->maxiter - it;
+    int rc = aslr_iterate_n(p, sp, it == 0, chunk, stream);
     if (rc) return rc;
-    if (!sp->fixed_iterations && poll_every > 0 && (it + 1) % poll_every == 0 && it + 1 < sp->maxiter) {
+    it += chunk;
+    if (polling && it < sp->maxiter) {
       int32_t active = 0;
       rc = aslr_count_active(p, stream, &active);
       if (rc) return rc;
-      if (active == 0) { ++it; break; }
+      if (active == 0) break;
     }
   }
   if (iters_done) *iters_done = it;

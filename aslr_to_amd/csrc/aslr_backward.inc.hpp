@@ -224,9 +224,9 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
 
   const int lane = threadIdx.x, team = lane / TEAM, lt = lane % TEAM, j = lt % NXP, h = lt / NXP;
   const int B = a.B, T = a.T;
-  const int bq = blockIdx.x * TPW + team;
-  const bool team_valid = team < TPW && bq < B;
-  const int b = team_valid ? bq : B - 1;
+  const int bq = a.b0 + blockIdx.x * TPW + team;
+  const bool team_valid = team < TPW && bq < a.b1;
+  const int b = team_valid ? bq : a.b1 - 1;
   const bool col_valid = j < NX;
   const int jj = col_valid ? j : NX - 1;
   const bool writer = team_valid && col_valid && h == 0;
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
   int done = 0, feasible = TI[ASLR_TI_FEASIBLE * B + b], status = TI[ASLR_TI_STATUS * B + b];
   if (!sp.standalone) {
     done = TI[ASLR_TI_DONE * B + b];
-    const int recalc = sp.wave_filter == 2 ? 0 : TI[ASLR_TI_RECALC * B + b]; // (2: the first launch of the pair did it)
+    const int recalc = TI[ASLR_TI_RECALC * B + b];
     if (!done && recalc) {
       if (!feasible) feasible = TI[ASLR_TI_GAPFLAG * B + b] ? 0 : 1;
       // cost_ = sum of node costs, in node order
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
       if (lt == 0 && team_valid) TF[ASLR_TF_COST * B + b] = csum;
     }
     wave_sync();
-    if (lt == 0 && team_valid && sp.wave_filter != 2) {
+    if (lt == 0 && team_valid) {
       TI[ASLR_TI_FEASIBLE * B + b] = feasible;
       TI[ASLR_TI_ACCEPTED * B + b] = -1;
       TI[ASLR_TI_GAPFLAG * B + b] = 0;
@@ -267,10 +267,6 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
   }
   bool need = team_valid && !done;
   if (__ballot(need) == 0ull) return;
-  if (sp.wave_filter) { // one launch of a pair: the gap-aware body takes the waves with an infeasible trajectory
-    const bool some_infeasible = __ballot(need && !feasible) != 0ull;
-    if (some_infeasible != (sp.wave_filter == 1)) return;
-  }
   double xreg = TF[ASLR_TF_XREG * B + b];
   const bool fddp = GAPS && sp.solver == ASLR_SOLVER_FDDP;
   const bool box = BOX && sp.solver == ASLR_SOLVER_BOXDDP && feasible;
@@ -650,27 +646,9 @@ __global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, Mod
 template <int NX, int NU, int HS, int TPWA = 0>
 int launch_backward_t(const KArgs &k, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st) {
   using C = BwdCfg<NX, NU, HS, TPWA>;
-  const int blocks = (k.B + C::TPW - 1) / C::TPW;
+  const int blocks = (k.b1 - k.b0 + C::TPW - 1) / C::TPW;
   const size_t lds = C::DMA ? 0 : (size_t)C::TPW * C::LDS_TEAM * sizeof(double); // (DMA: allocated statically)
   const bool box = sd.solver == ASLR_SOLVER_BOXDDP;
-  if (!sd.standalone && !all_feasible && sd.solver != ASLR_SOLVER_FDDP && !getenv("ASLR_BWD_SINGLE")) {
-    // DDP / BoxDDP solves: every trajectory is feasible from its first accepted step on, and the sweep without the gap
-    // terms is leaner -- but which trajectories are there is known on the device only.  Two launches, each wave picks
-    // the one for it: the gap-aware body does the bookkeeping of every wave and sweeps those with an infeasible
-    // trajectory, the lean body sweeps the others.  (One kernel choosing per wave between both bodies inlined was
-    // measured slower than the gap-aware body alone.)
-    SolverDev s1 = sd, s2 = sd;
-    s1.wave_filter = 1; s2.wave_filter = 2;
-    if (box) {
-      hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, true, true>), dim3(blocks), dim3(64), lds, st, k, s1, lim);
-      hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, true, false>), dim3(blocks), dim3(64), lds, st, k, s2, lim);
-    } else {
-      hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, false, true>), dim3(blocks), dim3(64), lds, st, k, s1, lim);
-      hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, false, false>), dim3(blocks), dim3(64), lds, st, k, s2, lim);
-    }
-    HIP_TRY(hipGetLastError());
-    return ASLR_OK;
-  }
   if (box && !all_feasible) hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, true, true>), dim3(blocks), dim3(64), lds, st, k, sd, lim);
   else if (box) hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, true, false>), dim3(blocks), dim3(64), lds, st, k, sd, lim);
   else if (!all_feasible) hipLaunchKernelGGL((backward_kernel<NX, NU, HS, TPWA, false, true>), dim3(blocks), dim3(64), lds, st, k, sd, lim);

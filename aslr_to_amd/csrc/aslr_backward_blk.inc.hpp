@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
   const bool wave0 = tid < 64;
   const int wv = tid >> 6, li = tid & 15, lk = (tid & 63) >> 4; // MFMA lane roles
   constexpr int NKS = NX / 4;
-  const int B = a.B, T = a.T, b = blockIdx.x;
+  const int B = a.B, T = a.T, b = a.b0 + blockIdx.x;
   int32_t *TI = a.traj_i;
   double *TF = a.traj_f;
 
@@ -528,7 +528,7 @@ int launch_backward_blk(const KArgs &k, const SolverDev &sd, bool all_feasible, 
   // ASLR_BLK_MFMA=0 selects the vector-FMA products (comparison runs; both paths give the same bits)
   const char *e = getenv("ASLR_BLK_MFMA");
   const bool mfma = e ? atoi(e) != 0 : true;
-  const dim3 grid(k.B), block(BwdBlk<NX, NU>::NT);
+  const dim3 grid(k.b1 - k.b0), block(BwdBlk<NX, NU>::NT);
   if (mfma) {
     if (all_feasible) hipLaunchKernelGGL((backward_blk_kernel<NX, NU, false, true>), grid, block, 0, st, k, sd);
     else hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true, true>), grid, block, 0, st, k, sd);

@@ -25,9 +25,9 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
   __shared__ int act[64];
 
   const int lane = threadIdx.x, t = blockIdx.y, B = a.B, T = a.T;
-  const int b0 = blockIdx.x * 64, bq = b0 + lane;
-  const bool valid = bq < B;
-  const int b = valid ? bq : B - 1;
+  const int b0 = a.b0 + blockIdx.x * 64, bq = b0 + lane; // (b0: first trajectory of this block)
+  const bool valid = bq < a.b1;
+  const int b = valid ? bq : a.b1 - 1;
   const int32_t *TI = a.traj_i;
 
   int acc = -1, recalc = 1, done = 0, feasible = 1;

@@ -4,7 +4,7 @@
 namespace aslr {
 
 int launch_calc_nj2(const KArgs &k, int dam, bool diff, int mode, double th_gaptol, hipStream_t st) {
-  dim3 grid((k.B + 63) / 64, k.T + 1), block(64);
+  dim3 grid((k.b1 - k.b0 + 63) / 64, k.T + 1), block(64);
   if (dam == ASLR_DAM_SEA) {
     if (k.planar) {
       if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, true, true>), grid, block, 0, st, k, mode, th_gaptol);

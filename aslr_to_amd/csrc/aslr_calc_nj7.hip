@@ -5,11 +5,11 @@
 namespace aslr {
 
 int launch_calc_nj7(const KArgs &k, int dam, bool diff, int mode, double th_gaptol, hipStream_t st) {
-  dim3 grid((k.B + 63) / 64, k.T + 1), block(64);
+  dim3 grid((k.b1 - k.b0 + 63) / 64, k.T + 1), block(64);
   if (dam == ASLR_DAM_SEA) {
     {
       if (diff) { // rigid-body part by 8-lane teams (aslr_calc_team.inc.hpp), then products + costs + record per lane
-        const dim3 tgrid((k.B + 7) / 8, k.T + 1);
+        const dim3 tgrid((k.b1 - k.b0 + 7) / 8, k.T + 1);
         hipLaunchKernelGGL((dyn_team_kernel<7, 0>), tgrid, block, 0, st, k, mode);
         hipLaunchKernelGGL((dyn_team_kernel<7, 1>), tgrid, block, 0, st, k, mode);
         hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_SEA, true, false, true>), grid, block, 0, st, k, mode, th_gaptol);

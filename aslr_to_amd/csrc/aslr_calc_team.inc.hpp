@@ -135,9 +135,9 @@ __global__ void __launch_bounds__(64) dyn_team_kernel(KArgs a, int mode) {
   __shared__ double sm[8 * C::TEAM_LDS];
   const int tid = threadIdx.x, team = tid >> 3, c = tid & 7;
   const int B = a.B, T = a.T, t = blockIdx.y;
-  const int bq = blockIdx.x * 8 + team;
-  const bool valid = bq < B;
-  const int b = valid ? bq : B - 1;
+  const int bq = a.b0 + blockIdx.x * 8 + team;
+  const bool valid = bq < a.b1;
+  const int b = valid ? bq : a.b1 - 1;
   const int32_t *TI = a.traj_i;
   int acc = -1, recalc = 1, done = 0;
   if (mode & kModeCommit) acc = TI[ASLR_TI_ACCEPTED * B + b];

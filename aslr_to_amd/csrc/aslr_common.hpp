@@ -38,6 +38,9 @@ struct KArgs {
   double *traj_f;
   int32_t *traj_i;
   int32_t B, T;
+  // trajectories [b0, b1) of the shard this launch covers (the whole shard unless the handle iterates sub-shards on
+  // their own streams, aslr_set_subshards): array strides stay B, grids are sized for b1 - b0
+  int32_t b0, b1;
   int32_t planar; // the chain qualifies for the planar dynamics path (DevDesc::planar.ok)
   int32_t planar_reach; // ... and the frame-placement costs for the closed-form residual (DevDesc::planar.reach_ok)
   double *iter_log;  // per-iteration log [log_cap][ASLR_LOG_COUNT][B] (aslr_set_iteration_log), or nullptr
@@ -68,10 +71,6 @@ struct SolverDev {
   double boxqp_th_acceptstep, boxqp_th_grad, boxqp_reg;
   int32_t standalone; // 1: API-level single pass (no retry, no solver-state updates)
   int32_t store_v;    // 1: write VX / VXX
-  // backward sweep launched as a pair (DDP / BoxDDP solves): 1 = first launch, gap-aware body: does the per-trajectory
-  // bookkeeping of every wave, then sweeps only the waves that hold an infeasible trajectory; 2 = second launch, lean
-  // body: no bookkeeping, sweeps the waves whose live trajectories are all feasible; 0 = single launch
-  int32_t wave_filter;
 };
 
 // control limits of the (at most ASLR_MAX_MODELS) action models, passed by value so the backward loop

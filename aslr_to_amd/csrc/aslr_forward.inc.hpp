@@ -29,9 +29,9 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
   using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
   const int lane = threadIdx.x, team = lane / TEAM, al = lane % TEAM;
   const int B = a.B, T = a.T;
-  const int bq = blockIdx.x * TPW + team;
-  const bool team_valid = team < TPW && bq < B;
-  const int b = team_valid ? bq : B - 1;
+  const int bq = a.b0 + blockIdx.x * TPW + team;
+  const bool team_valid = team < TPW && bq < a.b1;
+  const int b = team_valid ? bq : a.b1 - 1;
   int32_t *TI = a.traj_i;
   double *TF = a.traj_f;
   const int done = sp.standalone ? 0 : TI[ASLR_TI_DONE * B + b];
@@ -145,9 +145,9 @@ __global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
   using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
   const int B = a.B, T = a.T, t = blockIdx.y, ai = blockIdx.z;
-  const int bq = blockIdx.x * 64 + threadIdx.x;
-  const bool valid = bq < B;
-  const int b = valid ? bq : B - 1;
+  const int bq = a.b0 + blockIdx.x * 64 + threadIdx.x;
+  const bool valid = bq < a.b1;
+  const int b = valid ? bq : a.b1 - 1;
   const int done = sp.standalone ? 0 : a.traj_i[ASLR_TI_DONE * B + b];
   if (!valid || done) return;
   const size_t TB1 = (size_t)(T + 1) * B, TB = (size_t)T * B, tb = (size_t)t * B + b;
@@ -186,8 +186,8 @@ __global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
 template <int TAG>
 __global__ void __launch_bounds__(64) sum_cost_kernel(KArgs a, SolverDev sp) {
   const int B = a.B, T = a.T, s = blockIdx.y;
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
+  const int b = a.b0 + blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.b1) return;
   if (!sp.standalone && a.traj_i[ASLR_TI_DONE * B + b]) return;
   const double *src = a.cost_try + (size_t)s * (T + 1) * B + b;
   double acc = 0.0;
@@ -206,8 +206,8 @@ __global__ void __launch_bounds__(64) sum_cost_kernel(KArgs a, SolverDev sp) {
 template <int TAG>
 __global__ void __launch_bounds__(64) select_kernel(KArgs a, SolverDev sp) {
   const int B = a.B;
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
+  const int b = a.b0 + blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.b1) return;
   int32_t *TI = a.traj_i;
   double *TF = a.traj_f;
   if (!sp.standalone && TI[ASLR_TI_DONE * B + b]) return;

@@ -3,8 +3,9 @@
 
 namespace aslr {
 int launch_forward_nj2(const KArgs &k, int dam, const SolverDev &sd, const ModelLimits &lim, hipStream_t st) {
-  dim3 grid((k.B + ASLR_ROLLOUT_TPW - 1) / ASLR_ROLLOUT_TPW), block(64), cgrid((k.B + 63) / 64, k.T + 1, ASLR_NALPHA), sgrid((k.B + 63) / 64),
-      cblock(64), ugrid((k.B + 63) / 64, ASLR_NALPHA);
+  const int nb = k.b1 - k.b0; // trajectories of this launch
+  dim3 grid((nb + ASLR_ROLLOUT_TPW - 1) / ASLR_ROLLOUT_TPW), block(64), cgrid((nb + 63) / 64, k.T + 1, ASLR_NALPHA), sgrid((nb + 63) / 64),
+      cblock(64), ugrid((nb + 63) / 64, ASLR_NALPHA);
   if (dam == ASLR_DAM_SEA) {
     if (k.planar) {
       if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_kernel<2, ASLR_DAM_SEA, true, true>), grid, block, 0, st, k, sd, lim);

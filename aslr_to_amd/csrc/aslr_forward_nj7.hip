@@ -4,13 +4,14 @@
 
 namespace aslr {
 int launch_forward_nj7(const KArgs &k, int dam, const SolverDev &sd, const ModelLimits &lim, hipStream_t st) {
-  dim3 block(64), cgrid((k.B + 63) / 64, k.T + 1, ASLR_NALPHA), sgrid((k.B + 63) / 64),
-      cblock(64), ugrid((k.B + 63) / 64, ASLR_NALPHA);
+  const int nb = k.b1 - k.b0; // trajectories of this launch
+  dim3 block(64), cgrid((nb + 63) / 64, k.T + 1, ASLR_NALPHA), sgrid((nb + 63) / 64),
+      cblock(64), ugrid((nb + 63) / 64, ASLR_NALPHA);
   if (dam == ASLR_DAM_SEA) {
     {
       // one block of 16 eight-lane teams per trajectory (aslr_forward_team.inc.hpp)
-      if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_team_kernel<7, true>), dim3(k.B), dim3(128), 0, st, k, sd, lim);
-      else hipLaunchKernelGGL((rollout_team_kernel<7, false>), dim3(k.B), dim3(128), 0, st, k, sd, lim);
+      if (sd.solver == ASLR_SOLVER_FDDP) hipLaunchKernelGGL((rollout_team_kernel<7, true>), dim3(nb), dim3(128), 0, st, k, sd, lim);
+      else hipLaunchKernelGGL((rollout_team_kernel<7, false>), dim3(nb), dim3(128), 0, st, k, sd, lim);
       hipLaunchKernelGGL((trial_cost_kernel<7, ASLR_DAM_SEA, false>), cgrid, cblock, 0, st, k, sd);
     }
     hipLaunchKernelGGL((sum_cost_kernel<7>), ugrid, block, 0, st, k, sd);

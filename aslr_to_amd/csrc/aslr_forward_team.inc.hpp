@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(128) rollout_team_kernel(KArgs a, SolverDev sp
   constexpr int NX = C::NX, NU = C::NU, NSLOT = C::NSLOT;
   __shared__ double sm[2 * C::STG + 16 * C::TEAM_LDS];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, team = tid >> 3, c = tid & 7;
-  const int B = a.B, T = a.T, b = blockIdx.x;
+  const int B = a.B, T = a.T, b = a.b0 + blockIdx.x;
   int32_t *TI = a.traj_i;
   double *TF = a.traj_f;
   if (!sp.standalone && TI[ASLR_TI_DONE * B + b]) return;

@@ -166,6 +166,15 @@ class Engine(object):
     def iterate(self, sp, first):
         self._call("aslr_iterate", C.byref(sp), 1 if first else 0, self._stream())
 
+    def iterate_n(self, sp, first, n):
+        """n lock-step iterations in one ABI call (sub-shards run them free of each other, see set_subshards)."""
+        self._call("aslr_iterate_n", C.byref(sp), 1 if first else 0, int(n), self._stream())
+
+    def set_subshards(self, n):
+        """Iterate the shard as n (1..4) sub-shards on internal streams: same results, bit for bit; the serial sweeps
+        of one sub-shard overlap the streaming kernels of the others (include/aslr_to_amd.h: aslr_set_subshards)."""
+        self._call("aslr_set_subshards", int(n))
+
     def iterate_timed(self, sp, first=False):
         """-> (calc_ms, backward_ms, forward_ms) of one iteration, from HIP events on the launch stream."""
         ms = (C.c_float * 3)()

@@ -50,11 +50,12 @@ def algorithmic_bytes(nx, nu):
 
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (separate --pmc passes of this
-    same command, profiles/r01/bench_pmc.csv): WRITE_SIZE + 2 x FETCH_SIZE, both in KiB -- the gfx950
+    same command with --subshards 1, profiles/rNN/bench_pmc.csv): WRITE_SIZE + 2 x FETCH_SIZE, both in KiB -- the gfx950
     correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE counts wide coalesced reads at half).
     None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01", "bench_pmc.csv")
-    if not os.path.exists(path):
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, "bench_pmc.csv") for r in ("r02", "r01"))
+                 if os.path.exists(p)), None)
+    if path is None:
         return None
     import csv
     fetch = write = None
@@ -142,6 +143,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--subshards", type=int, default=4,
+                    help="iterate each GPU's shard as this many sub-shards on internal streams (1 = off)")
     ap.add_argument("--converge-mode", action="store_true",
                     help="also time the example's own solve (th_stop 1e-7, maxiter 400) after the measured region")
     args = ap.parse_args()
@@ -183,19 +186,23 @@ def main():
     e = problem.engine
     sp = scenarios.solver_params(sc, fixed_iterations=1, maxiter=args.warmup + args.steps)
     e.set_candidate(None, None)  # cold start, as examples/two_dof_vsa_boxddp.py:81
+    # The shard is iterated as sub-shards on internal streams (same results bit for bit: trajectories are independent;
+    # the one-wave-per-SIMD sweeps of a sub-shard run under the streaming kernels of the others).  The K steps are
+    # enqueued by one aslr_iterate_n call, which forks from / joins the caller's stream around them.
+    e.set_subshards(args.subshards)
 
-    for i in range(args.warmup):
-        e.iterate(sp, i == 0)
+    if args.warmup > 0:
+        e.iterate_n(sp, True, args.warmup)
     dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        e.iterate(sp, args.warmup == 0 and i == 0)
+    e.iterate_n(sp, args.warmup == 0, args.steps)
     torch.cuda.synchronize(dev)
     dist.barrier()
     elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
 
-    # per-kernel durations (HIP events on the launch stream), a few more iterations of the same solve
+    # per-kernel durations: HIP events on the launch stream around each phase, with the whole shard as ONE launch per
+    # kernel (aslr_iterate_timed does not use the sub-shard streams), a few more iterations of the same solve
     nprobe = 10
     acc = [0.0, 0.0, 0.0]
     for _ in range(nprobe):
@@ -250,6 +257,7 @@ def main():
         "config": {"workload": "two_dof_vsa_boxddp (examples/two_dof_vsa_boxddp.py, T=100): SolverBoxDDP, "
                                "cold start, fixed-iteration mode, full 10-alpha line search every iteration",
                    "batch_per_gpu": Bg, "global_batch": Bg * world, "T": T, "nx": e.nx, "nu": e.nu,
+                   "subshards_per_gpu": args.subshards,
                    "sharding": "contiguous batch blocks, no data-path collective"},
         "ranks": {"world_size": ranks_seen, "backend": backend,
                   "launcher": "bench.py" if os.environ.get("ASLR_BENCH_SELF_LAUNCHED") == "1" else
@@ -261,9 +269,11 @@ def main():
         "line_search_rollouts_per_s": 10 * Bg * world * args.steps / elapsed,   # every step length is rolled out
         "converge_mode": converge,   # --converge-mode
         "kernel_ms": dict(zip(names, k_ms)),
+        "kernel_ms_note": "whole-shard launches on one stream (sub-shards off), HIP events; their sum is the "
+                          "iteration without overlap, ms_per_step the iteration with the sub-shard streams",
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc_names[dom]),
-                     "traffic_note": "bytes per launch, rocprofv3 PMC summary committed under profiles/r01 (not live)",
+                     "traffic_note": "bytes per launch, newest rocprofv3 PMC summary committed under profiles/ (not live)",
                      "algorithmic_bytes_per_launch": launch_bytes,
                      "algorithmic_bytes_per_knot_step": phase_bytes[dom],
                      "knot_steps_per_launch": Bg * T},

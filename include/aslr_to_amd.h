@@ -289,6 +289,17 @@ int aslr_solve(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t poll_e
 /* one lock-step DDP iteration (calcDiff sweep + backward pass + line search), the unit the
  * benchmark's "step" times.  `first` != 0 re-initialises the per-trajectory solver state. */
 int aslr_iterate(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream);
+/* `n` lock-step iterations (aslr_iterate n times; `first` applies to the first of them).  With sub-shards
+ * (aslr_set_subshards) each sub-shard runs its n iterations on its own stream, free of the others; the caller's stream
+ * is forked from on entry and joined on exit, so for the caller the call is "n iterations enqueued on my stream". */
+int aslr_iterate_n(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, int32_t n, void *stream);
+/* Iterate the shard as `n` (1..4) contiguous sub-shards of trajectories, each on an internal HIP stream created here
+ * (boundaries on multiples of 64 trajectories).  Trajectories are independent (one ShootingProblem per solve in the
+ * reference, examples/two_dof_vsa_boxddp.py:66), so results do not depend on n, bit for bit; what changes is the
+ * schedule: the latency-bound sweeps (backward pass, rollout: one wave per SIMD) of one sub-shard overlap the
+ * streaming kernels (calc / calcDiff, trial costs) of the others.  Applies to aslr_iterate_n and aslr_solve;
+ * aslr_iterate_timed and the stand-alone passes always cover the whole shard on the caller's stream.  n = 1: off. */
+int aslr_set_subshards(aslr_problem_t *p, int32_t n);
 /* aslr_iterate with HIP events recorded on `stream` around each of its three kernels
  * (calc/calcDiff sweep, backward pass, forward pass + line search); waits for the last event and
  * returns the three durations in milliseconds.  Measurement aid for bench.py's roofline leg. */

@@ -463,3 +463,41 @@ def test_engine_runs_on_its_own_device_whatever_the_current_one():
     e.calc_diff()
     torch.cuda.synchronize()
     assert torch.isfinite(e.region(_abi.R_COST)).all()
+
+
+def test_subshards_change_the_schedule_not_the_results():
+    """aslr_set_subshards: the shard iterated as 1, 2, 3, 4 sub-shards on internal streams gives the same bits
+    (trajectories are independent), for a batch that does not divide into 64-trajectory blocks evenly, through
+    aslr_iterate_n and through aslr_solve with convergence polling."""
+    import torch
+    from aslr_to_amd.engine import Engine
+    sc = scenarios.two_dof_vsa_boxddp(B=333, T=25, seed=9)
+    low = scenarios.lower(sc)
+    sp_fixed = scenarios.solver_params(sc, fixed_iterations=1, maxiter=12)
+    sp_conv = scenarios.solver_params(sc, maxiter=40)
+    ref = None
+    for n in (1, 2, 3, 4):
+        e = Engine(low)
+        e.set_subshards(n)
+        e.set_candidate(None, None)
+        e.iterate_n(sp_fixed, True, 5)
+        e.iterate_n(sp_fixed, False, 7)
+        e.finalize()
+        torch.cuda.synchronize()
+        a = (e.region(_abi.R_XS).clone(), e.region(_abi.R_US).clone(), e.region(_abi.R_TRAJ_I).clone(),
+             e.region(_abi.R_TRAJ_F).clone())
+        e.set_candidate(None, None)
+        iters = e.solve(sp_conv, poll_every=3)
+        torch.cuda.synchronize()
+        b = (e.region(_abi.R_XS).clone(), e.region(_abi.R_US).clone(), e.traj_i(_abi.TI_ITER).clone(),
+             e.traj_i(_abi.TI_STATUS).clone(), iters)
+        if ref is None:
+            ref = (a, b)
+            assert int(a[2][_abi.TI_ITER].min()) == 12
+            continue
+        same = lambda x, y: torch.equal(torch.nan_to_num(x), torch.nan_to_num(y)) if x.is_floating_point() else torch.equal(x, y)
+        for x, y in zip(ref[0], a):   # (TRAJ_F holds NaN for failed line-search trials)
+            assert same(x, y), n
+        for x, y in zip(ref[1][:4], b[:4]):
+            assert same(x, y), n
+        assert ref[1][4] == b[4]
