@@ -40,7 +40,10 @@ __global__ void reset_accepted_kernel(KArgs a) {
 // =================================================================================================
 // host side: handle, workspace carving, dispatch
 // =================================================================================================
-constexpr int kMaxSub = 4; // HIP maps streams onto 4 hardware queues by default: more sub-shards than that serialise
+// Sub-shard 0 runs on the caller's stream, the others on internal ones.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware
+// queues (4 unless that environment variable says otherwise): more streams in use than queues serialise them (measured:
+// 5 streams on 4 queues run 1.6x SLOWER than one), so 4 sub-shards is the default ceiling and more need the variable.
+constexpr int kMaxSub = 8;
 
 struct aslr_problem {
   aslr_problem_desc_t desc; // host copy (pointers nulled)
@@ -508,12 +511,12 @@ int iterate_range(aslr_problem *p, const aslr_solver_params_t *sp, int first, in
 // fork: the sub-shard streams wait for what the caller's stream has enqueued so far
 int sub_fork(aslr_problem *p, hipStream_t st) {
   HIP_TRY(hipEventRecord(p->sub_fork, st));
-  for (int s = 0; s < p->nsub; ++s) HIP_TRY(hipStreamWaitEvent(p->sub_stream[s], p->sub_fork, 0));
+  for (int s = 1; s < p->nsub; ++s) HIP_TRY(hipStreamWaitEvent(p->sub_stream[s], p->sub_fork, 0));
   return ASLR_OK;
 }
 // join: the caller's stream waits for every sub-shard stream
 int sub_join(aslr_problem *p, hipStream_t st) {
-  for (int s = 0; s < p->nsub; ++s) {
+  for (int s = 1; s < p->nsub; ++s) {
     HIP_TRY(hipEventRecord(p->sub_join[s], p->sub_stream[s]));
     HIP_TRY(hipStreamWaitEvent(st, p->sub_join[s], 0));
   }
@@ -562,7 +565,7 @@ int aslr_iterate_n(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t fi
   if (int rc = sub_fork(p, st)) return rc;
   for (int it = 0; it < n; ++it)
     for (int s = 0; s < p->nsub; ++s)
-      if (int rc = iterate_range(p, sp, first && it == 0, p->sub_b[s], p->sub_b[s + 1], p->sub_stream[s])) return rc;
+      if (int rc = iterate_range(p, sp, first && it == 0, p->sub_b[s], p->sub_b[s + 1], s == 0 ? st : p->sub_stream[s])) return rc;
   return sub_join(p, st);
 }
 

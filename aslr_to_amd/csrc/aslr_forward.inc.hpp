@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(64) select_kernel(KArgs a, SolverDev sp) {
     if (xreg == sp.reg_max) { status |= ASLR_ST_REG_MAX; fin = 1; }
   }
   const double stop = TF[ASLR_TF_STOP * B + b];
+  const int status_cb = status; // what a callback of this iteration reads: Crocoddyl calls them before its convergence test
   if (!fin && !sp.fixed_iterations && was_feasible && stop < sp.th_stop) { status |= ASLR_ST_CONVERGED; fin = 1; }
   const int it = TI[ASLR_TI_ITER * B + b];
   TI[ASLR_TI_ITER * B + b] = it + 1;
@@ -282,7 +283,7 @@ __global__ void __launch_bounds__(64) select_kernel(KArgs a, SolverDev sp) {
     lg[(size_t)ASLR_LOG_DV * B] = dV;
     lg[(size_t)ASLR_LOG_DVEXP * B] = dVexp;
     lg[(size_t)ASLR_LOG_ACCEPTED * B] = (double)accepted;
-    lg[(size_t)ASLR_LOG_STATUS * B] = (double)status;
+    lg[(size_t)ASLR_LOG_STATUS * B] = (double)status_cb;
     lg[(size_t)ASLR_LOG_FEASIBLE * B] = (double)feas;
   }
   TI[ASLR_TI_NTRIALS * B + b] += (accepted >= 0 ? accepted + 1 : ASLR_NALPHA);

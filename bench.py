@@ -153,6 +153,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # read by the HIP runtime at initialisation (sub-shard streams)
     # stdout carries the ONE JSON line and nothing else: whatever the libraries below print there (gloo's connection
     # notes, ROCm warnings) goes to stderr instead; the line is written to the saved descriptor at the end
     sys.stdout.flush()

@@ -228,7 +228,7 @@ enum {
   ASLR_LOG_D1, ASLR_LOG_D2, /* solver.expectedImprovement() (CallbackLogger.grads = -d2)        */
   ASLR_LOG_DV, ASLR_LOG_DVEXP,
   ASLR_LOG_ACCEPTED,  /* index of the accepted step length, -1: every trial rejected            */
-  ASLR_LOG_STATUS,    /* ASLR_ST_* bits after the iteration                                     */
+  ASLR_LOG_STATUS,    /* ASLR_ST_* bits as a callback of the iteration sees them (before the convergence test) */
   ASLR_LOG_FEASIBLE,  /* solver.isFeasible after the iteration                                  */
   ASLR_LOG_COUNT
 };
@@ -293,8 +293,9 @@ int aslr_iterate(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t firs
  * (aslr_set_subshards) each sub-shard runs its n iterations on its own stream, free of the others; the caller's stream
  * is forked from on entry and joined on exit, so for the caller the call is "n iterations enqueued on my stream". */
 int aslr_iterate_n(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, int32_t n, void *stream);
-/* Iterate the shard as `n` (1..4) contiguous sub-shards of trajectories, each on an internal HIP stream created here
- * (boundaries on multiples of 64 trajectories).  Trajectories are independent (one ShootingProblem per solve in the
+/* Iterate the shard as `n` (1..8) contiguous sub-shards of trajectories: the first on the caller's stream, the others on
+ * internal HIP streams created here (boundaries on multiples of 64 trajectories).  More streams in use than the HIP
+ * runtime has hardware queues (GPU_MAX_HW_QUEUES, default 4) serialise: n <= 4 unless that variable is raised.  Trajectories are independent (one ShootingProblem per solve in the
  * reference, examples/two_dof_vsa_boxddp.py:66), so results do not depend on n, bit for bit; what changes is the
  * schedule: the latency-bound sweeps (backward pass, rollout: one wave per SIMD) of one sub-shard overlap the
  * streaming kernels (calc / calcDiff, trial costs) of the others.  Applies to aslr_iterate_n and aslr_solve;

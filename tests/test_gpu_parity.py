@@ -439,3 +439,37 @@ def test_edge_sizes_single_knot_single_trajectory(oracle):
     e.solve(scenarios.solver_params(sc, maxiter=0))
     _sync()
     np.testing.assert_array_equal(_np(e.xs), xs0)
+
+
+def test_c5_horizon_full_solves_match_oracle(oracle):
+    """The C5 problem at its full horizon (7-DoF SEA, nx = 28, T = 150): 16 trajectories solved to convergence by
+    SolverFDDP (the solver the SEA example uses, examples/two_dof_sea.py:69) through the block / team kernels, against
+    the oracle: iteration counts, decision bits of the status words, and xs / us / cost of the converged ones within
+    the north_star tolerances (relative to the size of the iterates: a cold-started arm swings through ~1e2 rad/s)."""
+    import os
+    import _parity
+    nth = min(16, len(os.sched_getaffinity(0)))
+    sc = scenarios.talos_arm_sea(B=16, T=150, seed=0)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc, solver="SolverFDDP")
+    ref = oracle.solve(low, sp, nthreads=nth)
+    e = _engine(low)
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=4)
+    _sync()
+    it_g, it_r = _np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER]
+    st_r = ref["traj_i"][_abi.TI_STATUS]
+    conv = (st_r & _abi.ST_CONVERGED) != 0
+    assert conv.sum() >= 12
+    # trajectories that converge take the same number of iterations; the one that does not (and one that stops at the
+    # regularisation ceiling after a single iteration) must end with the same outcome bits
+    np.testing.assert_array_equal(it_g[conv], it_r[conv])
+    _parity.assert_status_words_match(_np(e.traj_i(_abi.TI_STATUS)), st_r, max_note_flips=2)
+    X, U = _np(e.region(_abi.R_XS)), _np(e.region(_abi.R_US))
+    scale = np.maximum(1.0, np.maximum(np.abs(ref["xs"]).max(axis=(0, 2)), np.abs(ref["us"]).max(axis=(0, 2))))
+    dx = np.abs(X - ref["xs"]).max(axis=(0, 2)) / scale
+    du = np.abs(U - ref["us"]).max(axis=(0, 2)) / scale
+    dc = np.abs(_np(e.traj_f(_abi.TF_COST)) - ref["traj_f"][_abi.TF_COST])
+    print("C5 horizon: converged %d / 16, max rel |dx| %.2e |du| %.2e, |dcost| %.2e" % (conv.sum(), dx[conv].max(), du[conv].max(), dc[conv].max()))
+    assert dx[conv].max() < 1e-6 and du[conv].max() < 1e-6
+    assert (dc[conv] < 1e-4 * np.maximum(1.0, np.abs(ref["traj_f"][_abi.TF_COST][conv]))).all()

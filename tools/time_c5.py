@@ -17,3 +17,17 @@ for i in range(5): e.iterate(sp, i == 0)
 torch.cuda.synchronize()
 print("B=%d 7-DoF SEA DDP T=150: iterate %.1f us, backward %.1f us, forward %.1f us, calc_diff %.1f us, calc %.1f us" % (
     B, timeit(lambda: e.iterate(sp, False)), timeit(lambda: e.backward_pass(sp)), timeit(lambda: e.forward_pass(sp)), timeit(e.calc_diff), timeit(e.calc)))
+
+# per-iteration phase times of a cold-started solve (HIP events) next to the trajectories whose backward pass had to be
+# regularised and redone INSIDE the kernel (the sweep of a block is repeated until its Cholesky factorisations succeed, like
+# SolverDDP.solve's catch / increaseRegularization / retry): the launch lasts as long as its slowest block
+e.set_candidate(None, None)
+spc = scenarios.solver_params(sc, solver=(sys.argv[2] if len(sys.argv) > 2 else "SolverDDP"), fixed_iterations=1)
+prev = None
+for i in range(12):
+    ms = e.iterate_timed(spc, i == 0)
+    xr = e.traj_f(A.TF_XREG).cpu().numpy()
+    st = e.traj_i(A.TI_STATUS).cpu().numpy()
+    nerr = int(((st & A.ST_BACKWARD_ERR) != 0).sum())
+    print("iteration %2d: calcDiff %.3f ms, backward %.3f ms, forward %.3f ms; trajectories with a regularised-and-redone backward pass so far %d, max xreg %.0e"
+          % (i, ms[0], ms[1], ms[2], nerr, xr.max()))
