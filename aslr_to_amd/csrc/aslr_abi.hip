@@ -62,6 +62,7 @@ struct aslr_problem {
   hipStream_t sub_stream[kMaxSub];
   hipEvent_t sub_fork, sub_join[kMaxSub];
   bool have_sub;
+  unsigned sub_flags;
   // model-only chunks of the DERIV records (cost-weight diagonals): const_ok = the cost stacks allow skipping them,
   // const_written = a sweep that evaluated every knot of every trajectory has put them in place
   bool const_ok, const_written;
@@ -455,7 +456,8 @@ int aslr_problem_destroy(aslr_problem_t *p) {
   if (p->h_done) (void)hipHostFree(p->h_done);
   if (p->have_ev) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(p->ev[i]);
   if (p->have_sub) {
-    for (int i = 0; i < kMaxSub; ++i) { (void)hipStreamDestroy(p->sub_stream[i]); (void)hipEventDestroy(p->sub_join[i]); }
+    for (int i = 0; i < kMaxSub; ++i)
+      if (p->sub_stream[i]) { (void)hipStreamDestroy(p->sub_stream[i]); (void)hipEventDestroy(p->sub_join[i]); }
     (void)hipEventDestroy(p->sub_fork);
   }
   delete p;
@@ -531,12 +533,17 @@ int aslr_set_subshards(aslr_problem_t *p, int32_t n) {
   const int blocks = (B + 63) / 64;
   if (n > blocks) n = blocks;
   if (n > 1 && !p->have_sub) {
-    for (int i = 0; i < kMaxSub; ++i) {
-      HIP_TRY(hipStreamCreateWithFlags(&p->sub_stream[i], hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&p->sub_join[i], hipEventDisableTiming));
-    }
+    const char *eb = getenv("ASLR_SUB_BLOCKING");
+    const unsigned flags = (eb && atoi(eb)) ? hipStreamDefault : hipStreamNonBlocking;
+    for (int i = 0; i < kMaxSub; ++i) { p->sub_stream[i] = nullptr; p->sub_join[i] = nullptr; }
     HIP_TRY(hipEventCreateWithFlags(&p->sub_fork, hipEventDisableTiming));
     p->have_sub = true;
+    p->sub_flags = flags;
+  }
+  for (int i = 1; i < n; ++i) { // (streams are created as they are first needed: unused ones would still take queue slots)
+    if (p->sub_stream[i]) continue;
+    HIP_TRY(hipStreamCreateWithFlags(&p->sub_stream[i], p->sub_flags));
+    HIP_TRY(hipEventCreateWithFlags(&p->sub_join[i], hipEventDisableTiming));
   }
   p->nsub = n;
   for (int s = 0; s <= n; ++s) {
