@@ -501,3 +501,56 @@ def test_subshards_change_the_schedule_not_the_results():
         for x, y in zip(ref[1][:4], b[:4]):
             assert same(x, y), n
         assert ref[1][4] == b[4]
+
+
+def test_vsa_on_the_seven_joint_chain_at_the_model_level(oracle):
+    """VSA actuation on the 7-joint arm (nx = 28, nu = 14): calc / calcDiff of the model and of a shooting problem run on
+    the GPU and match the oracle; the analytic Fx, Fu, Lx, Lu pass the reference's numdiff acceptance technique
+    (unittest/test_free_placementcost_free_fwddyn.py:34-46); the solver entry points decline with a message."""
+    model = example_robot_data.load('talos_arm').model
+    state = aslr_to.StateMultibodyASR(model)
+    actuation = aslr_to.VSAASRActuation(state)
+    nu = 2 * actuation.nu
+    assert nu == 14
+    costs = crocoddyl.CostModelSum(state, nu)
+    reach = aslr_to.ResidualModelFramePlacementASR(state, model.getFrameId("gripper_left_joint"),
+                                                   pinocchio.SE3(np.eye(3), np.array([0.1, 0.2, -0.3])), nu)
+    costs.addCost("reach", crocoddyl.CostModelResidual(state, reach), 2.0)
+    costs.addCost("effort", crocoddyl.CostModelResidual(state, crocoddyl.ResidualModelControl(state, nu)), 1e-2)
+    dam = aslr_to.DifferentialFreeFwdDynamicsModelVSA(state, actuation, costs)
+    running = aslr_to.IntegratedActionModelEulerASR(dam, 1e-2)
+    terminal = aslr_to.IntegratedActionModelEulerASR(dam, 0.0)
+    rng = np.random.default_rng(21)
+    x = rng.uniform(-0.6, 0.6, 28)
+    u = np.concatenate([rng.uniform(-1, 1, 7), rng.uniform(0.5, 3.0, 7)])
+    d = dam.createData()
+    dam.calc(d, x, u)
+    dam.calcDiff(d, x, u)
+    problem = crocoddyl.ShootingProblem(np.zeros(28), [running] * 3, terminal)
+    ref = oracle.dam(problem.lowered, 0, x, u)
+    for k in ("xout", "Fx", "Fu", "Lx", "Lu", "Lxx", "Luu"):
+        scale = max(1.0, np.abs(ref[k]).max())
+        assert np.abs(getattr(d, k) - ref[k]).max() < 1e-9 * scale, k
+    assert d.cost == pytest.approx(ref["cost"], rel=1e-11)
+
+    def acc(xx, uu):
+        dd = dam.createData()
+        dam.calc(dd, xx, uu)
+        return dd.xout.copy(), dd.cost
+    assert np.allclose(d.Fx, _numdiff(lambda z: acc(z, u)[0], x), atol=6.3e-3)
+    assert np.allclose(d.Fu, _numdiff(lambda z: acc(x, z)[0], u), atol=6.3e-3)
+    assert np.allclose(d.Lx, _numdiff(lambda z: acc(z, u)[1], x).ravel(), atol=3e-2)
+    assert np.allclose(d.Lu, _numdiff(lambda z: acc(x, z)[1], u).ravel(), atol=3e-2)
+    # the shooting-problem sweeps
+    xs = rng.uniform(-0.3, 0.3, (4, 28))
+    us = np.concatenate([rng.uniform(-1, 1, (3, 7)), rng.uniform(0.5, 3.0, (3, 7))], axis=1)
+    total = problem.calcDiff(xs, us)
+    kr = [oracle.knot(problem.lowered, 0, xs[t], us[t]) for t in range(3)]
+    assert total == pytest.approx(sum(k["cost"] for k in kr) + oracle.knot(problem.lowered, 1, xs[3], None)["cost"], rel=1e-11)
+    datas = problem.runningDatas.tolist()
+    for t in range(3):
+        np.testing.assert_allclose(datas[t].xnext, kr[t]["xnext"], atol=1e-11)
+        assert np.abs(datas[t].Fx - kr[t]["Fx"]).max() < 1e-9 * max(1.0, np.abs(kr[t]["Fx"]).max())
+        assert np.abs(datas[t].Fu - kr[t]["Fu"]).max() < 1e-9 * max(1.0, np.abs(kr[t]["Fu"]).max())
+    with pytest.raises(_abi.AslrError, match="model-level"):
+        crocoddyl.SolverDDP(problem).solve([], [], 3)
