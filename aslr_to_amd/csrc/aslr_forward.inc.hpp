@@ -54,7 +54,9 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
   }
   const typename CH::Consts cc(D, true); // (true: this kernel loops over knots -- sin / cos constants in registers)
   ModelRegs<NJ, NU> mr;
-  int m_loaded = -1;
+  int m_loaded = -1, lim_has = 0;
+  double lim_lb[NU], lim_ub[NU]; // control limits of the loaded model (kernel arguments behind a runtime index: scalar loads)
+  ASLR_UNROLL for (int i = 0; i < NU; ++i) { lim_lb[i] = 0.0; lim_ub[i] = 0.0; }
   // Per-knot inputs shared by the step lengths of a trajectory -- [K | xs | us | k | gaps | Vxx f] -- are fetched ONCE
   // per team, one knot ahead, straight into LDS (global_load_lds_dwordx4: lane lt fetches the 16-byte pieces lt and
   // lt + 16 of the list; element e of team tm lands at (e / 32) * 128 + 32 tm + e % 32 of the parity buffer).
@@ -117,15 +119,20 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
       u[i] = s;
     }
     const int m_now = mi;
-    if (box && lim.has[m_now]) {
-      ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = fmin(fmax(u[i], lim.lb[m_now][i]), lim.ub[m_now][i]);
+    const DevModel &dm = D.models[m_now];
+    if (m_now != m_loaded) { // wave-uniform: model constants and control limits, re-read only when the model changes
+      mr.load(dm);
+      m_loaded = m_now;
+      lim_has = lim.has[m_now];
+      ASLR_UNROLL for (int i = 0; i < NU; ++i) { lim_lb[i] = lim.lb[m_now][i]; lim_ub[i] = lim.ub[m_now][i]; }
+    }
+    if (box && lim_has) {
+      ASLR_UNROLL for (int i = 0; i < NU; ++i) u[i] = fmin(fmax(u[i], lim_lb[i]), lim_ub[i]);
     }
     if (lane_on) {
       ASLR_UNROLL for (int p = 0; p < NU / 2; ++p)
         *reinterpret_cast<double2 *>(a.us_try + cand_piece<NU>(ai, t, b, p, B, T)) = make_double2(u[2 * p], u[2 * p + 1]);
     }
-    const DevModel &dm = D.models[m_now];
-    if (m_now != m_loaded) { mr.load(dm); m_loaded = m_now; } // wave-uniform
     double xnext[NX], c;
     knot_eval<NJ, DAM, kEvalDyn, CH>(cc, mr, dm, nullptr, x, u, xnext, c, nullptr);
     double mx = 0.0;
