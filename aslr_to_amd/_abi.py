@@ -76,6 +76,13 @@ class SolverParams(C.Structure):
                 ("boxqp_reg", _d)]
 
 
+class Pool(C.Structure):
+    """aslr_pool_t: device pointers of a pool solve (aslr_solve_pool)."""
+    _fields_ = [("P", _i), ("_pad0", _i), ("x0", C.c_void_p), ("frame_ref", C.c_void_p), ("xs_out", C.c_void_p),
+                ("us_out", C.c_void_p), ("stat_f", C.c_void_p), ("stat_i", C.c_void_p), ("slot_problem", C.c_void_p),
+                ("counters", C.c_void_p)]
+
+
 class Region(C.Structure):
     _fields_ = [("offset", C.c_int64), ("bytes", C.c_int64)]
 
@@ -140,7 +147,7 @@ EXPORTED_SYMBOLS = [
     "aslr_calc", "aslr_calc_diff", "aslr_backward_pass", "aslr_forward_pass", "aslr_solve",
     "aslr_iterate", "aslr_iterate_timed", "aslr_finalize", "aslr_count_active", "aslr_dam_eval", "aslr_quasi_static", "aslr_last_error",
     "aslr_dam_residuals", "aslr_residual_len", "aslr_frame_placement", "aslr_set_iteration_log",
-    "aslr_iterate_n", "aslr_set_subshards",
+    "aslr_iterate_n", "aslr_set_subshards", "aslr_solve_pool",
 ]
 
 
@@ -204,6 +211,8 @@ def load_library():
     lib.aslr_frame_placement.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), i32, vp, i64, vp, vp]
     lib.aslr_iterate_n.restype = C.c_int
     lib.aslr_iterate_n.argtypes = [vp, C.POINTER(SolverParams), i32, i32, vp]
+    lib.aslr_solve_pool.restype = C.c_int
+    lib.aslr_solve_pool.argtypes = [vp, C.POINTER(SolverParams), C.POINTER(Pool), i32, i32, vp, C.POINTER(i32)]
     lib.aslr_set_subshards.restype = C.c_int
     lib.aslr_set_subshards.argtypes = [vp, i32]
     lib.aslr_set_iteration_log.restype = C.c_int

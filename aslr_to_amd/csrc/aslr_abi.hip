@@ -35,6 +35,77 @@ __global__ void reset_accepted_kernel(KArgs a) {
   if (b < a.b1) a.traj_i[ASLR_TI_ACCEPTED * a.B + b] = -1;
 }
 
+// aslr_solve_pool: flush the slots whose problem has stopped and hand them the next problem of the pool.
+// One 64-thread block per slot; nothing to do for a slot that is still iterating.
+struct PoolDev {
+  int32_t P, nx, nu;
+  const double *x0, *frame_ref;
+  double *xs_out, *us_out, *stat_f;
+  int32_t *stat_i, *slot_problem, *counters;
+};
+__global__ void __launch_bounds__(64) pool_refill_kernel(KArgs a, PoolDev pl, double reg0, int is_feasible) {
+  const int b = blockIdx.x, tid = threadIdx.x, B = a.B, T = a.T, nx = pl.nx, nu = pl.nu;
+  int32_t *TI = a.traj_i;
+  double *TF = a.traj_f;
+  const int j = pl.slot_problem[b];
+  const int done = TI[ASLR_TI_DONE * B + b];
+  if (j >= 0 && !done) return; // still iterating
+  __shared__ int next_j;
+  if (j >= 0) { // ---- flush: the last accepted candidate is the solution (solver.xs / solver.us) ----
+    const int acc = TI[ASLR_TI_ACCEPTED * B + b];
+    double *xo = pl.xs_out + (size_t)j * (T + 1) * nx, *uo = pl.us_out + (size_t)j * T * nu;
+    for (int t = tid; t <= T; t += 64) {
+      for (int i = 0; i < nx; ++i) {
+        const size_t src = acc >= 0 ? ((size_t)acc * (T + 1) + t) * ASLR_CAND_SLAB(B, nx) + ASLR_CAND_OFFSET(b, i, nx) : 0;
+        xo[(size_t)t * nx + i] = acc >= 0 ? a.xs_try[src] : a.xs[((size_t)t * B + b) * nx + i];
+      }
+      if (t < T)
+        for (int i = 0; i < nu; ++i) {
+          const size_t src = acc >= 0 ? ((size_t)acc * T + t) * ASLR_CAND_SLAB(B, nu) + ASLR_CAND_OFFSET(b, i, nu) : 0;
+          uo[(size_t)t * nu + i] = acc >= 0 ? a.us_try[src] : a.us[((size_t)t * B + b) * nu + i];
+        }
+    }
+    if (tid == 0) {
+      pl.stat_f[4 * (size_t)j + 0] = TF[ASLR_TF_COST * B + b];
+      pl.stat_f[4 * (size_t)j + 1] = TF[ASLR_TF_STOP * B + b];
+      pl.stat_f[4 * (size_t)j + 2] = TF[ASLR_TF_XREG * B + b];
+      pl.stat_f[4 * (size_t)j + 3] = TF[ASLR_TF_STEP * B + b];
+      pl.stat_i[2 * (size_t)j + 0] = TI[ASLR_TI_ITER * B + b];
+      pl.stat_i[2 * (size_t)j + 1] = TI[ASLR_TI_STATUS * B + b];
+      atomicAdd(&pl.counters[1], 1);
+    }
+  }
+  __syncthreads(); // (the flush reads this slot's columns; the refill below overwrites them)
+  if (tid == 0) {
+    const int n = atomicAdd(&pl.counters[0], 1);
+    next_j = n < pl.P ? n : -1;
+  }
+  __syncthreads();
+  const int jn = next_j;
+  if (jn < 0) { // pool exhausted: the slot idles (DONE stays set)
+    if (tid == 0) { pl.slot_problem[b] = -1; TI[ASLR_TI_DONE * B + b] = 1; TI[ASLR_TI_ACCEPTED * B + b] = -1; }
+    return;
+  }
+  // ---- refill: cold start of problem jn in slot b (solve([], [], maxiter): xs = 0, us = 0) ----
+  for (int t = tid; t <= T; t += 64) {
+    const size_t tb = (size_t)t * B + b;
+    for (int i = 0; i < nx; ++i) { a.xs[tb * nx + i] = 0.0; a.gaps[tb * nx + i] = 0.0; a.vxxf[tb * nx + i] = 0.0; }
+    if (t < T)
+      for (int i = 0; i < nu; ++i) { a.us[tb * nu + i] = 0.0; a.kff[tb * nu + i] = 0.0; }
+  }
+  if (tid < nx) const_cast<double *>(a.x0)[(size_t)b * nx + tid] = pl.x0[(size_t)jn * nx + tid];
+  if (tid < 12 && pl.frame_ref && a.frame_ref) const_cast<double *>(a.frame_ref)[12 * (size_t)b + tid] = pl.frame_ref[12 * (size_t)jn + tid];
+  if (tid == 0) { // per-trajectory solver state, as init_state_kernel sets it
+    for (int r = 0; r < ASLR_TF_COUNT; ++r) TF[r * B + b] = 0.0;
+    for (int r = 0; r < ASLR_TI_COUNT; ++r) TI[r * B + b] = 0;
+    TF[ASLR_TF_XREG * B + b] = reg0;
+    TI[ASLR_TI_FEASIBLE * B + b] = is_feasible;
+    TI[ASLR_TI_RECALC * B + b] = 1;
+    TI[ASLR_TI_ACCEPTED * B + b] = -1;
+    pl.slot_problem[b] = jn;
+  }
+}
+
 } // namespace
 
 // =================================================================================================
@@ -67,6 +138,7 @@ struct aslr_problem {
   // const_written = a sweep that evaluated every knot of every trajectory has put them in place
   bool const_ok, const_written;
   bool const_pending_full; // aslr_iterate_n: the first sweep of this call is the one that puts them in place
+  int pool_maxiter;        // > 0 inside aslr_solve_pool: trajectories stop by themselves after this many iterations
 };
 
 namespace {
@@ -242,7 +314,7 @@ SolverDev to_dev(const aslr_solver_params_t *sp, int standalone, int store_v) {
   s.reg_decfactor = sp->reg_decfactor;
   s.boxqp_maxiter = sp->boxqp_maxiter; s.boxqp_th_acceptstep = sp->boxqp_th_acceptstep;
   s.boxqp_th_grad = sp->boxqp_th_grad; s.boxqp_reg = sp->boxqp_reg;
-  s.standalone = standalone; s.store_v = store_v;
+  s.standalone = standalone; s.store_v = store_v; s.maxiter_traj = 0;
   return s;
 }
 
@@ -442,7 +514,7 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   k.traj_f = (double *)reg(ASLR_R_TRAJ_F); k.traj_i = (int32_t *)reg(ASLR_R_TRAJ_I);
   k.B = desc->B; k.T = desc->T;
   k.b0 = 0; k.b1 = desc->B;
-  p->nsub = 1; p->have_sub = false;
+  p->nsub = 1; p->have_sub = false; p->pool_maxiter = 0;
   p->sub_b[0] = 0; p->sub_b[1] = desc->B;
   k.planar = planar_ok;
   k.planar_reach = planar_reach;
@@ -501,9 +573,10 @@ int iterate_range(aslr_problem *p, const aslr_solver_params_t *sp, int first, in
     hipLaunchKernelGGL(init_state_kernel, dim3((b1 - b0 + 255) / 256), dim3(256), 0, st, p->k, reg0, sp->is_feasible);
     if (hipGetLastError() != hipSuccess) rc = ASLR_E_HIP;
   }
-  const SolverDev sd = to_dev(sp, 0, 0);
+  SolverDev sd = to_dev(sp, 0, 0);
+  sd.maxiter_traj = p->pool_maxiter;
   // (the model-only record chunks are marked written by a sweep that covers the WHOLE shard: the last sub-shard's)
-  if (!rc) rc = launch_calc(p, true, kModeCommit | kModeSolver, sp->th_gaptol, st, first != 0 && b1 == p->desc.B && p->const_pending_full);
+  if (!rc) rc = launch_calc(p, true, kModeCommit | kModeSolver, sp->th_gaptol, st, (first != 0 || p->pool_maxiter > 0) && b1 == p->desc.B && p->const_pending_full);
   if (!rc) rc = launch_backward(p, sd, st);
   if (!rc) rc = launch_forward(p, sd, st);
   p->k = full;
@@ -559,7 +632,7 @@ int aslr_iterate_n(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t fi
   if (int rc = solver_unsupported(p)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int B = p->desc.B;
-  p->const_pending_full = !p->const_written;
+  if (p->pool_maxiter == 0) p->const_pending_full = !p->const_written; // (aslr_solve_pool sets it itself)
   if (p->nsub <= 1) {
     for (int it = 0; it < n; ++it)
       if (int rc = iterate_range(p, sp, first && it == 0, 0, B, st)) return rc;
@@ -655,6 +728,65 @@ int aslr_solve(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t poll_e
   }
   if (iters_done) *iters_done = it;
   return aslr_finalize(p, stream);
+}
+
+int aslr_solve_pool(aslr_problem_t *p, const aslr_solver_params_t *sp, const aslr_pool_t *pool, int32_t refill_every,
+                    int32_t poll_every, void *stream, int32_t *iters_done) {
+  if (!p || !sp || !pool || pool->P <= 0 || !pool->x0 || !pool->xs_out || !pool->us_out || !pool->stat_f || !pool->stat_i ||
+      !pool->slot_problem || !pool->counters || sp->maxiter <= 0 || sp->fixed_iterations)
+    return ASLR_E_INVALID;
+  if (pool->frame_ref && !p->k.frame_ref) {
+    snprintf(g_err, sizeof g_err, "aslr_solve_pool: per-problem frame references need a problem created with a frame_ref table");
+    return ASLR_E_INVALID;
+  }
+  if (int rc = solver_unsupported(p)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int B = p->desc.B;
+  if (refill_every <= 0) refill_every = 4;
+  if (poll_every <= 0) poll_every = 4 * refill_every;
+  PoolDev pl;
+  pl.P = pool->P; pl.nx = p->nx; pl.nu = p->nu;
+  pl.x0 = pool->x0; pl.frame_ref = pool->frame_ref; pl.xs_out = pool->xs_out; pl.us_out = pool->us_out;
+  pl.stat_f = pool->stat_f; pl.stat_i = pool->stat_i; pl.slot_problem = pool->slot_problem; pl.counters = pool->counters;
+  const double reg0 = std::isnan(sp->reg_init) ? sp->reg_min : sp->reg_init;
+  // every slot starts idle; the first refill hands out the first B problems
+  HIP_TRY(hipMemsetAsync(pool->slot_problem, 0xFF, sizeof(int32_t) * B, st));
+  HIP_TRY(hipMemsetAsync(pool->counters, 0, sizeof(int32_t) * 2, st));
+  HIP_TRY(hipMemsetAsync(p->k.traj_i + (size_t)ASLR_TI_DONE * B, 0, sizeof(int32_t) * B, st));
+  aslr_solver_params_t spi = *sp;
+  const KArgs saved = p->k;
+  p->k.iter_log = nullptr; p->k.log_cap = 0; // (a slot's iteration index restarts with every problem)
+  p->pool_maxiter = sp->maxiter;
+  int it = 0, rc = ASLR_OK;
+  // the slowest possible schedule: every problem takes maxiter iterations, one wave of B problems after the other
+  const long long cap = ((long long)(pool->P + B - 1) / B + 1) * (long long)(sp->maxiter + refill_every);
+  bool first = true;
+  while (it < cap) {
+    hipLaunchKernelGGL(pool_refill_kernel, dim3(B), dim3(64), 0, st, p->k, pl, reg0, sp->is_feasible);
+    if (hipGetLastError() != hipSuccess) { rc = ASLR_E_HIP; break; }
+    // (the first sweep covers every slot when the pool fills them all: it puts the model-only record chunks in place)
+    p->const_pending_full = first && pool->P >= B && !p->const_written;
+    rc = aslr_iterate_n(p, &spi, 0, refill_every, stream);
+    if (rc) break;
+    first = false;
+    it += refill_every;
+    if (it % poll_every < refill_every) {
+      int32_t fin = 0;
+      // (flush before counting: the kernel above ran before these iterations)
+      hipLaunchKernelGGL(pool_refill_kernel, dim3(B), dim3(64), 0, st, p->k, pl, reg0, sp->is_feasible);
+      if (hipMemcpyAsync(p->h_done, pool->counters + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess) { rc = ASLR_E_HIP; break; }
+      fin = p->h_done[0];
+      if (fin >= pool->P) break;
+    }
+  }
+  p->pool_maxiter = 0;
+  p->k = saved;
+  if (iters_done) *iters_done = it;
+  if (rc) return rc;
+  hipLaunchKernelGGL(reset_accepted_kernel, dim3((B + 255) / 256), dim3(256), 0, st, p->k);
+  HIP_TRY(hipGetLastError());
+  return ASLR_OK;
 }
 
 int aslr_dam_eval(aslr_problem_t *p, int32_t model_index, int32_t n, const double *x, const double *u, double *xout,

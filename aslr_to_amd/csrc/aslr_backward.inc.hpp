@@ -212,8 +212,11 @@ ASLR_DEV void dma_record(const char *g, unsigned recD_addr, int lt, std::integer
 
 // BOX: SolverBoxDDP gains may be needed (solver is BoxDDP); GAPS: infeasible candidates may be present
 // (gap terms, FDDP expected-improvement terms).  A wave whose trajectories need neither runs the lean variant.
+#ifndef ASLR_BWD_WAVES
+#define ASLR_BWD_WAVES 1 // (experiments: waves per SIMD the HS = 4 variant must fit)
+#endif
 template <int NX, int NU, int HS, int TPWA, bool BOX, bool GAPS>
-__global__ void __launch_bounds__(64) backward_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
+__global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
   using C = BwdCfg<NX, NU, HS, TPWA>;
   constexpr int NXP = C::NXP, TEAM = C::TEAM, TPW = C::TPW, RPL = C::RPL, REC = C::REC;
   // The work arrays are a static allocation in the DMA configuration: the compiler then knows they cannot overlap

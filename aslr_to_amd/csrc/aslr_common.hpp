@@ -71,6 +71,7 @@ struct SolverDev {
   double boxqp_th_acceptstep, boxqp_th_grad, boxqp_reg;
   int32_t standalone; // 1: API-level single pass (no retry, no solver-state updates)
   int32_t store_v;    // 1: write VX / VXX
+  int32_t maxiter_traj; // > 0: a trajectory stops by itself after this many iterations (pool solves); 0: the host loop bounds them
 };
 
 // control limits of the (at most ASLR_MAX_MODELS) action models, passed by value so the backward loop

@@ -277,6 +277,7 @@ __global__ void __launch_bounds__(64) select_kernel(KArgs a, SolverDev sp) {
   const double stop = TF[ASLR_TF_STOP * B + b];
   const int status_cb = status; // what a callback of this iteration reads: Crocoddyl calls them before its convergence test
   if (!fin && !sp.fixed_iterations && was_feasible && stop < sp.th_stop) { status |= ASLR_ST_CONVERGED; fin = 1; }
+  if (sp.maxiter_traj > 0 && TI[ASLR_TI_ITER * B + b] + 1 >= sp.maxiter_traj) fin = 1; // (pool solves: maxiter reached)
   const int it = TI[ASLR_TI_ITER * B + b];
   TI[ASLR_TI_ITER * B + b] = it + 1;
   if (a.iter_log && it < a.log_cap) { // what the callbacks of this iteration would read (aslr_set_iteration_log)

@@ -251,6 +251,40 @@ class Engine(object):
                        C.c_void_p(du.data_ptr()), C.c_void_p(r.data_ptr()), self._stream())
         return r[:, :nr].cpu().numpy()
 
+    def solve_pool(self, x0s, frame_refs, sp, refill_every=4, poll_every=16):
+        """A pool of P problems of this engine's structure solved through its B slots, each to its own convergence
+        (aslr_solve_pool: stopped slots are flushed and refilled on the device; every problem is cold-started).
+        x0s [P, nx], frame_refs [P, 12] or None (host or device).  -> dict of device tensors: xs [P, T+1, nx],
+        us [P, T, nu], cost / stop / x_reg / step [P], iters / status [P] (int32), and batch_iters (int)."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            x0 = torch.as_tensor(x0s, dtype=torch.float64, device=self.device).contiguous()
+            P = x0.shape[0]
+            if tuple(x0.shape) != (P, self.nx):
+                raise ValueError("x0s must have shape [P, nx=%d]" % self.nx)
+            fr = None
+            if frame_refs is not None:
+                fr = torch.as_tensor(frame_refs, dtype=torch.float64, device=self.device).contiguous()
+                if tuple(fr.shape) != (P, 12):
+                    raise ValueError("frame_refs must have shape [P, 12]")
+            xs = torch.empty((P, self.T + 1, self.nx), dtype=torch.float64, device=self.device)
+            us = torch.empty((P, self.T, self.nu), dtype=torch.float64, device=self.device)
+            sf = torch.zeros((P, 4), dtype=torch.float64, device=self.device)
+            si = torch.zeros((P, 2), dtype=torch.int32, device=self.device)
+            slot = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+            cnt = torch.zeros((2,), dtype=torch.int32, device=self.device)
+        pool = _abi.Pool()
+        pool.P = P
+        pool.x0, pool.frame_ref = x0.data_ptr(), (fr.data_ptr() if fr is not None else None)
+        pool.xs_out, pool.us_out, pool.stat_f, pool.stat_i = xs.data_ptr(), us.data_ptr(), sf.data_ptr(), si.data_ptr()
+        pool.slot_problem, pool.counters = slot.data_ptr(), cnt.data_ptr()
+        it = C.c_int32(0)
+        self._call("aslr_solve_pool", C.byref(sp), C.byref(pool), int(refill_every), int(poll_every), self._stream(),
+                   C.byref(it))
+        torch.cuda.synchronize(self.device)
+        return dict(xs=xs, us=us, cost=sf[:, 0], stop=sf[:, 1], x_reg=sf[:, 2], step=sf[:, 3], iters=si[:, 0],
+                    status=si[:, 1], batch_iters=it.value)
+
     def traj_f(self, row):
         return self.region(_abi.R_TRAJ_F)[row]
 

@@ -286,6 +286,33 @@ int aslr_forward_pass(aslr_problem_t *p, const aslr_solver_params_t *sp, void *s
  * host polls the active-trajectory count every `poll_every` iterations (one 4-byte D2H). */
 int aslr_solve(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t poll_every,
                void *stream, int32_t *iters_done);
+/* A POOL of P shooting problems of the same structure (same chain, models, T) solved through the B trajectory slots of
+ * the handle, each to its own convergence: the reference solves its problems one after the other
+ * (`solver.solve(...)` per problem, examples/two_dof_vsa_boxddp.py:81); a lock-step batch of B waits for its slowest
+ * member (BoxDDP at C3: 400 lock-step iterations where a trajectory needs 107 on average).  Here a slot whose problem has
+ * stopped (converged, regularisation at its maximum, or sp->maxiter iterations) is flushed to the outputs and refilled
+ * with the next problem of the pool every `refill_every` iterations, on the device, so the slots stay busy.
+ * Every problem is cold-started (xs = 0, us = 0: `solve([], [], maxiter)`) and goes through exactly the iterations
+ * aslr_solve would give it: results do not depend on B, on the slot or on refill_every, bit for bit.
+ * All pointers are DEVICE pointers owned by the caller. */
+typedef struct aslr_pool {
+  int32_t P;                  /* problems in the pool                                                          */
+  int32_t _pad0;
+  const double *x0;           /* [P][nx] initial states                                                        */
+  const double *frame_ref;    /* [P][12] reference placements (R row-major, p), or NULL; needs a problem created
+                                 with a frame_ref table                                                       */
+  double *xs_out;             /* [P][T+1][nx] solutions (batch-major)                                          */
+  double *us_out;             /* [P][T][nu]                                                                    */
+  double *stat_f;             /* [P][4]: cost, stop, x_reg, last step length                                   */
+  int32_t *stat_i;            /* [P][2]: iterations, ASLR_ST_* status word                                     */
+  int32_t *slot_problem;      /* [B] scratch: the problem in each slot (-1: idle)                              */
+  int32_t *counters;          /* [2] scratch: next problem to hand out, problems finished                      */
+} aslr_pool_t;
+/* `iters_done` (host, optional) receives the lock-step iterations launched.  The host polls the finished-problem
+ * counter every `poll_every` iterations (one 4-byte D2H). */
+int aslr_solve_pool(aslr_problem_t *p, const aslr_solver_params_t *sp, const aslr_pool_t *pool, int32_t refill_every,
+                    int32_t poll_every, void *stream, int32_t *iters_done);
+
 /* one lock-step DDP iteration (calcDiff sweep + backward pass + line search), the unit the
  * benchmark's "step" times.  `first` != 0 re-initialises the per-trajectory solver state. */
 int aslr_iterate(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t first, void *stream);

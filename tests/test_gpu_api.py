@@ -554,3 +554,38 @@ def test_vsa_on_the_seven_joint_chain_at_the_model_level(oracle):
         assert np.abs(datas[t].Fu - kr[t]["Fu"]).max() < 1e-9 * max(1.0, np.abs(kr[t]["Fu"]).max())
     with pytest.raises(_abi.AslrError, match="model-level"):
         crocoddyl.SolverDDP(problem).solve([], [], 3)
+
+
+def test_pool_solve_gives_every_problem_the_solve_it_would_get_in_a_batch():
+    """aslr_solve_pool: 300 problems streamed through 64 slots (stopped slots flushed and refilled on the device), each
+    cold-started and iterated to its own stop, against ONE lock-step batch solve of the same 300: identical bits per
+    problem, whatever the refill period and the sub-shard count; fewer lock-step iterations than 5 waves of 64 would
+    need back to back."""
+    import torch
+    from aslr_to_amd.engine import Engine
+    P, T, maxiter = 300, 30, 80
+    sc = scenarios.two_dof_vsa_boxddp(B=P, T=T, seed=4)
+    sp = scenarios.solver_params(sc, maxiter=maxiter)
+    full = Engine(scenarios.lower(sc))
+    full.set_candidate(None, None)
+    full.solve(sp, poll_every=8)
+    torch.cuda.synchronize()
+    X = full.region(_abi.R_XS).permute(1, 0, 2).contiguous()
+    U = full.region(_abi.R_US).permute(1, 0, 2).contiguous()
+    iters, status = full.traj_i(_abi.TI_ITER).clone(), full.traj_i(_abi.TI_STATUS).clone()
+    cost = full.traj_f(_abi.TF_COST).clone()
+    assert int(iters.min()) < int(iters.max())          # the problems really need different numbers of iterations
+    slots = dict(sc)
+    slots["x0"], slots["frame_refs"] = sc["x0"][:64], sc["frame_refs"][:64]
+    e = Engine(scenarios.lower(slots))
+    for refill_every, nsub in ((1, 1), (4, 1), (3, 2)):
+        e.set_subshards(nsub)
+        r = e.solve_pool(sc["x0"], sc["frame_refs"], sp, refill_every=refill_every, poll_every=8)
+        assert torch.equal(r["iters"], iters) and torch.equal(r["status"], status)
+        assert torch.equal(r["xs"], X) and torch.equal(r["us"], U)
+        assert torch.equal(r["cost"], cost)
+        waves = -(-P // 64)
+        assert r["batch_iters"] < waves * int(iters.max())
+    # a pool smaller than the slots, and a solver without bounds on the same engine afterwards
+    r = e.solve_pool(sc["x0"][:10], sc["frame_refs"][:10], sp)
+    assert torch.equal(r["xs"], X[:10]) and torch.equal(r["iters"], iters[:10])
