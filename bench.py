@@ -232,6 +232,23 @@ def main():
                     "useful_knot_steps_per_s": cstats["iters_sum"] * T / conv_wall,
                     "note": "th_stop 1e-7, maxiter 400, all trajectories iterate in lock-step until the last one "
                             "stops; useful = iterations each trajectory needed"}
+        # the same solves as a POOL: 4x as many problems streamed through the same slots (aslr_solve_pool: a slot whose
+        # problem has stopped is flushed and refilled on the device), so no slot waits for the batch's stragglers
+        npool = 4 * Bg
+        scp = scenarios.two_dof_vsa_boxddp(B=npool * world, T=T, seed=0)
+        lo = rank * npool
+        torch.cuda.synchronize(dev)
+        tp0 = time.perf_counter()
+        r = e.solve_pool(scp["x0"][lo:lo + npool], scp["frame_refs"][lo:lo + npool], spc, refill_every=4, poll_every=16)
+        torch.cuda.synchronize(dev)
+        pool_wall = dist.max_over_ranks(time.perf_counter() - tp0, dev)
+        pool_iters = dist.max_over_ranks(float(r["iters"].sum().item()), dev) if world == 1 else float(r["iters"].sum().item())
+        converge["pool"] = {"problems_per_gpu": npool, "slots_per_gpu": Bg, "wall_s": pool_wall,
+                            "lock_step_iterations": int(r["batch_iters"]),
+                            "converged": int(((r["status"] & _abi.ST_CONVERGED) != 0).sum().item()),
+                            "trajectory_iterations": pool_iters,
+                            "useful_knot_steps_per_s": pool_iters * T * world / pool_wall,
+                            "note": "rank-local counts; H2D of the pool's x0 / targets (2.6 MB per GPU) is inside wall_s"}
 
     if world > 1:
         torch.distributed.barrier()
