@@ -350,6 +350,23 @@ class SolverDDP(object):
             self._replay_callbacks()
         return bool(((st & _abi.ST_CONVERGED) != 0).all().item())
 
+    def solve_pool(self, x0s, frame_refs=None, maxiter=100, isFeasible=False, regInit=None, refill_every=4,
+                   poll_every=16):
+        """Solve MANY problems of this solver's structure (per-problem x0 and, optionally, frame-placement targets as
+        pinocchio.SE3 or [P, 12] arrays), each from a cold start to its own stop, streaming them through the problem's
+        trajectory slots (the loop `for x0 in x0s: solver.solve([], [], maxiter)` of a script, run on the device:
+        aslr_solve_pool).  -> dict of torch tensors: xs [P, T+1, nx], us [P, T, nu], cost, stop, x_reg, step, iters,
+        status [P], and batch_iters."""
+        sp = self._sp
+        sp.maxiter = int(maxiter)
+        sp.is_feasible = 1 if isFeasible else 0
+        sp.reg_init = float("nan") if regInit is None else float(regInit)
+        x0s = np.atleast_2d(np.asarray(x0s, dtype=np.float64))
+        fr = None
+        if frame_refs is not None:
+            fr = np.array([f.as12() if hasattr(f, "as12") else np.asarray(f, dtype=np.float64).reshape(12) for f in frame_refs])
+        return self.problem.engine.solve_pool(x0s, fr, sp, refill_every, poll_every)
+
     def iteration_log(self):
         """numpy [iterations, LOG_COUNT, B] of the last solve (needs callbacks or `keep_log = True`), trimmed to the
         iterations some trajectory ran; NaN where a trajectory had stopped.  Fields: _abi.LOG_*."""

@@ -31,3 +31,16 @@ for i in range(12):
     nerr = int(((st & A.ST_BACKWARD_ERR) != 0).sum())
     print("iteration %2d: calcDiff %.3f ms, backward %.3f ms, forward %.3f ms; trajectories with a regularised-and-redone backward pass so far %d, max xreg %.0e"
           % (i, ms[0], ms[1], ms[2], nerr, xr.max()))
+# the shard as sub-shards on streams (aslr_set_subshards)
+import time
+for k in (1, 2, 4):
+    e2 = Engine(low)
+    e2.set_subshards(k)
+    e2.set_candidate(None, None)
+    e2.iterate_n(spc, True, 8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e2.iterate_n(spc, False, 20)
+    torch.cuda.synchronize()
+    print("%d sub-shard(s): %.1f us per iteration" % (k, (time.perf_counter() - t0) / 20 * 1e6))
+    del e2
