@@ -3,13 +3,16 @@ on a side stream.  Usage: time_subshards.py [k ...]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("ASLR_LIB_OVERRIDE"):  # an experimental build of the library (tools/ubench/*.so)
+    from aslr_to_amd import _abi as _A
+    _A.lib_path = lambda: os.path.abspath(os.environ["ASLR_LIB_OVERRIDE"])
 from aslr_to_amd import scenarios
 from aslr_to_amd.engine import Engine
 ks = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
 sc = scenarios.two_dof_vsa_boxddp(B=4096, T=100)
 low = scenarios.lower(sc)
 sp = scenarios.solver_params(sc, fixed_iterations=1)
-for side in (False, True):
+for side in ((False, True) if not os.environ.get("ASLR_ONE_STREAM_KIND") else (False,)):
     st = torch.cuda.Stream() if side else torch.cuda.current_stream()
     with torch.cuda.stream(st):
         for k in ks:
