@@ -589,3 +589,26 @@ def test_pool_solve_gives_every_problem_the_solve_it_would_get_in_a_batch():
     # a pool smaller than the slots, and a solver without bounds on the same engine afterwards
     r = e.solve_pool(sc["x0"][:10], sc["frame_refs"][:10], sp)
     assert torch.equal(r["xs"], X[:10]) and torch.equal(r["iters"], iters[:10])
+
+
+@pytest.mark.parametrize("name,solver,P,slots,T,maxiter", [("two_dof_sea", "SolverFDDP", 150, 40, 25, 60),
+                                                          ("talos_arm_sea", "SolverFDDP", 14, 6, 20, 12)])
+def test_pool_solve_on_the_other_models_and_solvers(name, solver, P, slots, T, maxiter):
+    """The pool solve with gap-aware FDDP iterations (slots start infeasible) on the 2-DoF SEA arm and on the 7-joint chain
+    (block / team kernels, plain candidate slabs): bit-identical to one batch solve of the same problems."""
+    import torch
+    from aslr_to_amd.engine import Engine
+    sc = scenarios.SCENARIOS[name](B=P, T=T, seed=6)
+    sp = scenarios.solver_params(sc, solver=solver, maxiter=maxiter)
+    full = Engine(scenarios.lower(sc))
+    full.set_candidate(None, None)
+    full.solve(sp, poll_every=4)
+    torch.cuda.synchronize()
+    sub = dict(sc)
+    sub["x0"], sub["frame_refs"] = sc["x0"][:slots], sc["frame_refs"][:slots]
+    e = Engine(scenarios.lower(sub))
+    r = e.solve_pool(sc["x0"], sc["frame_refs"], sp, refill_every=2, poll_every=4)
+    assert torch.equal(r["iters"], full.traj_i(_abi.TI_ITER)) and torch.equal(r["status"], full.traj_i(_abi.TI_STATUS))
+    assert torch.equal(r["xs"], full.region(_abi.R_XS).permute(1, 0, 2).contiguous())
+    assert torch.equal(r["us"], full.region(_abi.R_US).permute(1, 0, 2).contiguous())
+    assert torch.equal(r["cost"], full.traj_f(_abi.TF_COST))
