@@ -74,7 +74,7 @@ def cpu_baseline(sc_fn, nthreads):
     """Oracle (CPU port) solving the first trajectories of the same batch in converge mode."""
     from aslr_to_amd import _abi, scenarios
     from oracle import pyoracle
-    nsample = 16 * nthreads
+    nsample = 64 * nthreads   # ~8 s of wall time on 16 host cores (~2 minutes of CPU work)
     sc = sc_fn(B=nsample, T=T, seed=0)
     low = scenarios.lower(sc)
     sp = scenarios.solver_params(sc)
@@ -82,8 +82,8 @@ def cpu_baseline(sc_fn, nthreads):
     r = pyoracle.solve(low, sp, nthreads=nthreads)
     dt = time.perf_counter() - t0
     iters = int(r["traj_i"][_abi.TI_ITER].sum())
-    # mode (i) of SURVEY.md 8(d): one thread, the reference's forced nthreads = 1 (first 8 trajectories)
-    sc1 = sc_fn(B=8, T=T, seed=0)
+    # mode (i) of SURVEY.md 8(d): one thread, the reference's forced nthreads = 1 (first 32 trajectories)
+    sc1 = sc_fn(B=32, T=T, seed=0)   # ~4 s
     low1 = scenarios.lower(sc1)
     t0 = time.perf_counter()
     r1 = pyoracle.solve(low1, scenarios.solver_params(sc1), nthreads=1)
