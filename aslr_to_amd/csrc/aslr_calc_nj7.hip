@@ -19,12 +19,7 @@ int launch_calc_nj7(const KArgs &k, int dam, bool diff, int mode, double th_gapt
     HIP_TRY(hipGetLastError());
     return ASLR_OK;
   }
-  if (dam == ASLR_DAM_VSA) { // model-level support (ShootingProblem.calc / calcDiff): the per-lane kernel
-    if (diff) hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_VSA, true, false>), grid, block, 0, st, k, mode, th_gaptol);
-    else hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_VSA, false, false>), grid, block, 0, st, k, mode, th_gaptol);
-    HIP_TRY(hipGetLastError());
-    return ASLR_OK;
-  }
+  if (dam == ASLR_DAM_VSA) return launch_calc_nj7_vsa(k, diff, mode, th_gaptol, st); // (aslr_calc_nj7_vsa.hip)
   snprintf(err_buf(), kErrLen, "calc: unsupported (nj=7, dam=%d)", dam);
   return ASLR_E_INVALID;
 }
@@ -38,11 +33,7 @@ int launch_dam_eval_nj7(const KArgs &k, int dam, int mi, int n, const double *x,
     HIP_TRY(hipGetLastError());
     return ASLR_OK;
   }
-  if (dam == ASLR_DAM_VSA) {
-    hipLaunchKernelGGL((dam_eval_kernel<7, ASLR_DAM_VSA, false>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, xout, cost, Fx, Fu, Lx, Lu, Lxx, Lxu, Luu);
-    HIP_TRY(hipGetLastError());
-    return ASLR_OK;
-  }
+  if (dam == ASLR_DAM_VSA) return launch_dam_eval_nj7_vsa(k, mi, n, x, u, xout, cost, Fx, Fu, Lx, Lu, Lxx, Lxu, Luu, st);
   snprintf(err_buf(), kErrLen, "dam_eval: unsupported (nj=7, dam=%d)", dam);
   return ASLR_E_INVALID;
 }
@@ -54,11 +45,7 @@ int launch_dam_residuals_nj7(const KArgs &k, int dam, int mi, int n, const doubl
     HIP_TRY(hipGetLastError());
     return ASLR_OK;
   }
-  if (dam == ASLR_DAM_VSA) {
-    hipLaunchKernelGGL((dam_residual_kernel<7, ASLR_DAM_VSA, false>), grid, block, 0, st, k.desc, mi, k.frame_ref, n, x, u, r, nr);
-    HIP_TRY(hipGetLastError());
-    return ASLR_OK;
-  }
+  if (dam == ASLR_DAM_VSA) return launch_dam_residuals_nj7_vsa(k, mi, n, x, u, r, nr, st);
   snprintf(err_buf(), kErrLen, "dam_residuals: unsupported (nj=7, dam=%d)", dam);
   return ASLR_E_INVALID;
 }

@@ -113,6 +113,10 @@ int launch_dam_residuals_nj7(const KArgs &k, int dam, int mi, int n, const doubl
 struct FrameArg { double R[9], p[3]; }; // local placement of a frame on its joint, by value
 int launch_frame_placement_nj2(const KArgs &k, int fj, const FrameArg &F, int n, const double *x, int64_t stride, double *out, hipStream_t st);
 int launch_frame_placement_nj7(const KArgs &k, int fj, const FrameArg &F, int n, const double *x, int64_t stride, double *out, hipStream_t st);
+int launch_calc_nj7_vsa(const KArgs &k, bool diff, int mode, double th_gaptol, hipStream_t st);
+int launch_dam_eval_nj7_vsa(const KArgs &k, int mi, int n, const double *x, const double *u, double *xout, double *cost,
+                            double *Fx, double *Fu, double *Lx, double *Lu, double *Lxx, double *Lxu, double *Luu, hipStream_t st);
+int launch_dam_residuals_nj7_vsa(const KArgs &k, int mi, int n, const double *x, const double *u, double *r, int nr, hipStream_t st);
 int launch_quasi_static_nj2(const KArgs &k, int dam, int maxiter, double tol, int32_t *iters, hipStream_t st);
 int launch_quasi_static_nj7(const KArgs &k, int dam, int maxiter, double tol, int32_t *iters, hipStream_t st);
 int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st);

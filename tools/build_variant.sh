@@ -8,7 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/aslr_to_amd/csrc
 make -s -j8 -C $C
 O=/tmp/aslr_variant_$NAME; mkdir -p $O
-ALL="aslr_abi aslr_calc_nj2 aslr_calc_nj7 aslr_backward_nx8 aslr_backward_nx28 aslr_forward_nj2 aslr_forward_nj7"
+ALL="aslr_abi aslr_calc_nj2 aslr_calc_nj7 aslr_calc_nj7_vsa aslr_backward_nx8 aslr_backward_nx28 aslr_forward_nj2 aslr_forward_nj7"
 OBJS=""
 for tu in $ALL; do
   if echo " $TUS " | grep -q " $tu "; then
