@@ -1404,6 +1404,9 @@ constexpr bool rec_elem_is_model_only() {
   constexpr int NX = L::NX;
   if (rec_elem_is_zero<NJ, NU, E>()) return true;
   if (SEA && E >= L::oFu && E < L::oLxx) return true;
+  // SEA: the motor rows of da_dx are [B^-1 K | -B^-1 K | 0 | 0] (free_fwddyn_asr.py:82-85) -- constants of the model, and
+  // so are the Fx rows built from them (rows nj .. 2nj-1 of each half of the Euler Jacobian, integrated_action.py:31-35)
+  if (SEA && E < L::oFu) { constexpr int r = E / NX; return (r % L::NV) >= NJ; }
   if (E >= L::oLxx && E < L::oLxu) {
     constexpr int e = E - L::oLxx, r = e / NX, cc = e % NX;
     return r == cc && r >= NJ;
