@@ -16,7 +16,9 @@ constexpr int kLdsStride = kChunk + 1; // odd stride: conflict-free ds_write_b64
 
 
 // PRE: the rigid-body part of the knot was computed by dyn_team_kernel (aslr_calc_team.inc.hpp) into DYN
-template <int NJ, int DAM, bool DIFF, bool PLANAR, bool PRE = false>
+// SKIPC: the model-only record chunks are in place (kModeSkipConst, known at launch): compiled out, and with them the
+// parts of the compact derivative set only they read (the steady-state sweeps of a solve run this variant)
+template <int NJ, int DAM, bool DIFF, bool PLANAR, bool PRE = false, bool SKIPC = false>
 __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int mode, double th_gaptol) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
   using RL = RecLayout<NJ, NU>;
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
     // chunks that depend on the model only (cost-weight diagonals of Lxx / Luu; all of Fu for SEA) are written by the
     // first full sweep
     if constexpr (rec_chunk_is_model_only<NJ, NU, c, kChunk, DAM == ASLR_DAM_SEA>()) {
-      if (mode & kModeSkipConst) return;
+      if constexpr (SKIPC) return;
     }
     if (compute) {
       static_for<0, kChunk>([&](auto ii) {

@@ -7,10 +7,12 @@ int launch_calc_nj2(const KArgs &k, int dam, bool diff, int mode, double th_gapt
   dim3 grid((k.b1 - k.b0 + 63) / 64, k.T + 1), block(64);
   if (dam == ASLR_DAM_SEA) {
     if (k.planar) {
-      if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, true, true>), grid, block, 0, st, k, mode, th_gaptol);
+      if (diff && (mode & kModeSkipConst)) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, true, true, false, true>), grid, block, 0, st, k, mode, th_gaptol);
+      else if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, true, true>), grid, block, 0, st, k, mode, th_gaptol);
       else hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, false, true>), grid, block, 0, st, k, mode, th_gaptol);
     } else {
-      if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, true, false>), grid, block, 0, st, k, mode, th_gaptol);
+      if (diff && (mode & kModeSkipConst)) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, true, false, false, true>), grid, block, 0, st, k, mode, th_gaptol);
+      else if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, true, false>), grid, block, 0, st, k, mode, th_gaptol);
       else hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_SEA, false, false>), grid, block, 0, st, k, mode, th_gaptol);
     }
     HIP_TRY(hipGetLastError());
@@ -18,10 +20,12 @@ int launch_calc_nj2(const KArgs &k, int dam, bool diff, int mode, double th_gapt
   }
   if (dam == ASLR_DAM_VSA) {
     if (k.planar) {
-      if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, true, true>), grid, block, 0, st, k, mode, th_gaptol);
+      if (diff && (mode & kModeSkipConst)) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, true, true, false, true>), grid, block, 0, st, k, mode, th_gaptol);
+      else if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, true, true>), grid, block, 0, st, k, mode, th_gaptol);
       else hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, false, true>), grid, block, 0, st, k, mode, th_gaptol);
     } else {
-      if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, true, false>), grid, block, 0, st, k, mode, th_gaptol);
+      if (diff && (mode & kModeSkipConst)) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, true, false, false, true>), grid, block, 0, st, k, mode, th_gaptol);
+      else if (diff) hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, true, false>), grid, block, 0, st, k, mode, th_gaptol);
       else hipLaunchKernelGGL((calc_kernel<2, ASLR_DAM_VSA, false, false>), grid, block, 0, st, k, mode, th_gaptol);
     }
     HIP_TRY(hipGetLastError());

@@ -12,7 +12,8 @@ int launch_calc_nj7(const KArgs &k, int dam, bool diff, int mode, double th_gapt
         const dim3 tgrid((k.b1 - k.b0 + 7) / 8, k.T + 1);
         hipLaunchKernelGGL((dyn_team_kernel<7, 0>), tgrid, block, 0, st, k, mode);
         hipLaunchKernelGGL((dyn_team_kernel<7, 1>), tgrid, block, 0, st, k, mode);
-        hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_SEA, true, false, true>), grid, block, 0, st, k, mode, th_gaptol);
+        if (mode & kModeSkipConst) hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_SEA, true, false, true, true>), grid, block, 0, st, k, mode, th_gaptol);
+        else hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_SEA, true, false, true>), grid, block, 0, st, k, mode, th_gaptol);
       }
       else hipLaunchKernelGGL((calc_kernel<7, ASLR_DAM_SEA, false, false>), grid, block, 0, st, k, mode, th_gaptol);
     }
