@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(64) pool_refill_kernel(KArgs a, PoolDev pl, do
   const int j = pl.slot_problem[b];
   const int done = TI[ASLR_TI_DONE * B + b];
   if (j >= 0 && !done) return; // still iterating
+  if (j < 0 && pl.counters[0] >= pl.P) return; // idle and nothing left to hand out (the counter only grows)
   __shared__ int next_j;
   if (j >= 0) { // ---- flush: the last accepted candidate is the solution (solver.xs / solver.us) ----
     const int acc = TI[ASLR_TI_ACCEPTED * B + b];
@@ -774,7 +775,8 @@ int aslr_solve_pool(aslr_problem_t *p, const aslr_solver_params_t *sp, const asl
       int32_t fin = 0;
       // (flush before counting: the kernel above ran before these iterations)
       hipLaunchKernelGGL(pool_refill_kernel, dim3(B), dim3(64), 0, st, p->k, pl, reg0, sp->is_feasible);
-      if (hipMemcpyAsync(p->h_done, pool->counters + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpyAsync(p->h_done, pool->counters + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
           hipStreamSynchronize(st) != hipSuccess) { rc = ASLR_E_HIP; break; }
       fin = p->h_done[0];
       if (fin >= pool->P) break;
