@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
   }
   const size_t tb = (size_t)t * B + b;
   const size_t TB1 = (size_t)(T + 1) * B, TB = (size_t)T * B;
+  ASLR_PROF_DECL;
 
   // ---- x, u of this knot (from the accepted candidate when there is one) ----
   double x[NX], u[NU];
@@ -81,6 +82,11 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
   }
   const bool compute = valid && recalc && !done && !(mode & kModeNoCompute);
   if (__ballot(compute) == 0ull) return; // wave-uniform
+#ifdef ASLR_BWD_PROFILE
+  { double wsum = 0.0; ASLR_UNROLL for (int i = 0; i < NX; ++i) wsum += x[i]; ASLR_UNROLL for (int i = 0; i < NU; ++i) wsum += u[i];
+    asm volatile("" : : "v"(wsum)); } // (profile build: the inputs have arrived)
+#endif
+  ASLR_PROF(0);
 
   const DevDesc &D = *a.desc;
   const DevModel &dm = D.models[node_model_at(a, t)];
@@ -98,6 +104,7 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
     constexpr int what = (DIFF ? kEvalDiff : (kEvalDyn | kEvalCost)) | (PRE ? (kEvalPre | kEvalSkipCost) : 0);
     knot_eval<NJ, DAM, what, CH>(cc, mr, dm, fref, x, t < T ? u : nullptr, xnext, cost, DIFF ? &kd : nullptr, nullptr,
                                  PRE ? a.dyn + tb * dyn_len_c(NJ) : nullptr);
+    ASLR_PROF(1);
     double *xn = a.xnext + tb * NX;
     ASLR_UNROLL for (int i = 0; i < NX; ++i) xn[i] = xnext[i];
     if constexpr (!PRE) a.cost[tb] = cost;
@@ -188,6 +195,9 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
     }
   }
   static_for<C1, REC / kChunk>(flush_chunk);
+  ASLR_PROF(2);
+  ASLR_PROF_COUNT(15);
+  ASLR_PROF_FLUSH;
   }
 }
 

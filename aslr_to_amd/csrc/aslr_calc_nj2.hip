@@ -85,3 +85,15 @@ int launch_quasi_static_nj2(const KArgs &k, int dam, int maxiter, double tol, in
 }
 
 } // namespace aslr
+
+#ifdef ASLR_BWD_PROFILE
+// profile builds only (tools/calc_regions.py): read / reset the region table of this translation unit
+extern "C" int aslr_debug_calc_prof(unsigned long long *out32, int reset) {
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(aslr::aslr_bwd_prof_dev), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(aslr::aslr_bwd_prof_dev), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
