@@ -178,3 +178,46 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in src and "aslr_cpu_" not in src and "aslr_oracle" not in src, f
+
+
+def test_cost_sum_orders_its_residuals_by_name_like_crocoddyl():
+    """data.r of a CostModelSum stacks the residual vectors in the order of the cost NAMES (Crocoddyl keeps its cost
+    items in a std::map), not in the order addCost was called -- which is the order the kernels evaluate them in."""
+    from aslr_to_amd import scenarios
+    dam = scenarios.two_dof_vsa_modified(B=1, T=1)["running"][0].differential
+    # insertion order: gripperPose (6), xReg (8), uReg (4), vsa (2)
+    raw = np.arange(20, dtype=float)
+    got = dam.costs.order_residuals(raw, 8, 4)
+    np.testing.assert_array_equal(got, np.concatenate([raw[0:6], raw[14:18], raw[18:20], raw[6:14]]))
+    assert dam.costs.nr == 20
+    with pytest.raises(ValueError):
+        dam.costs.order_residuals(raw[:-1], 8, 4)
+
+
+def test_parity_report_names_the_first_differing_decision():
+    """tests/_parity.py on hand-made logs: identical logs give no exception; a different accepted step length, an earlier
+    exit and a silent cost drift are each named at the right iteration."""
+    import _parity
+    from aslr_to_amd import _abi as A
+    n, B = 6, 4
+    lg = np.full((n, A.LOG_COUNT, B), np.nan)
+    for k in range(5):
+        lg[k, :, :] = 0.0
+        lg[k, A.LOG_COST] = 100.0 - k
+        lg[k, A.LOG_XREG] = 1e-9
+    lr = lg.copy()
+    assert all(_parity.first_decision_flip(lg, lr, b) is None for b in range(B))
+    lr[3, A.LOG_ACCEPTED, 1] = 2.0                      # trajectory 1: another step length at iteration 3
+    lr[4, :, 2] = np.nan                                # trajectory 2: the oracle stopped after iteration 3
+    lr[2:, A.LOG_COST, 3] += 1e-5                       # trajectory 3: costs drift apart from iteration 2 on
+    f1, f2 = _parity.first_decision_flip(lg, lr, 1), _parity.first_decision_flip(lg, lr, 2)
+    assert f1["kind"] == "line search" and f1["iteration"] == 3
+    assert f2["kind"] == "exit" and f2["iteration"] == 4
+    assert _parity.first_decision_flip(lg, lr, 3) is None and _parity.first_cost_drift(lg, lr, 3)[0] == 2
+    assert _parity.first_cost_drift(lg, lr, 0) is None
+    # status words: decision bits exactly, the overflow note within its allowance
+    _parity.assert_status_words_match(np.array([1, 9, 1, 2]), np.array([1, 1, 1, 2]))
+    with pytest.raises(AssertionError):
+        _parity.assert_status_words_match(np.array([1, 1, 1, 2]), np.array([1, 1, 3, 2]))
+    with pytest.raises(AssertionError):
+        _parity.assert_status_words_match(np.array([9, 9, 1, 2]), np.array([1, 1, 1, 2]))
