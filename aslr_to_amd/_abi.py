@@ -80,7 +80,7 @@ class Pool(C.Structure):
     """aslr_pool_t: device pointers of a pool solve (aslr_solve_pool)."""
     _fields_ = [("P", _i), ("_pad0", _i), ("x0", C.c_void_p), ("frame_ref", C.c_void_p), ("xs_out", C.c_void_p),
                 ("us_out", C.c_void_p), ("stat_f", C.c_void_p), ("stat_i", C.c_void_p), ("slot_problem", C.c_void_p),
-                ("counters", C.c_void_p)]
+                ("counters", C.c_void_p), ("xs_init", C.c_void_p), ("us_init", C.c_void_p)]
 
 
 class Region(C.Structure):

@@ -351,7 +351,7 @@ class SolverDDP(object):
         return bool(((st & _abi.ST_CONVERGED) != 0).all().item())
 
     def solve_pool(self, x0s, frame_refs=None, maxiter=100, isFeasible=False, regInit=None, refill_every=4,
-                   poll_every=16):
+                   poll_every=16, init_xs=None, init_us=None):
         """Solve MANY problems of this solver's structure (per-problem x0 and, optionally, frame-placement targets as
         pinocchio.SE3 or [P, 12] arrays), each from a cold start to its own stop, streaming them through the problem's
         trajectory slots (the loop `for x0 in x0s: solver.solve([], [], maxiter)` of a script, run on the device:
@@ -365,7 +365,7 @@ class SolverDDP(object):
         fr = None
         if frame_refs is not None:
             fr = np.array([f.as12() if hasattr(f, "as12") else np.asarray(f, dtype=np.float64).reshape(12) for f in frame_refs])
-        return self.problem.engine.solve_pool(x0s, fr, sp, refill_every, poll_every)
+        return self.problem.engine.solve_pool(x0s, fr, sp, refill_every, poll_every, init_xs, init_us)
 
     def iteration_log(self):
         """numpy [iterations, LOG_COUNT, B] of the last solve (needs callbacks or `keep_log = True`), trimmed to the

@@ -39,7 +39,7 @@ __global__ void reset_accepted_kernel(KArgs a) {
 // One 64-thread block per slot; nothing to do for a slot that is still iterating.
 struct PoolDev {
   int32_t P, nx, nu;
-  const double *x0, *frame_ref;
+  const double *x0, *frame_ref, *xs_init, *us_init;
   double *xs_out, *us_out, *stat_f;
   int32_t *stat_i, *slot_problem, *counters;
 };
@@ -87,12 +87,18 @@ __global__ void __launch_bounds__(64) pool_refill_kernel(KArgs a, PoolDev pl, do
     if (tid == 0) { pl.slot_problem[b] = -1; TI[ASLR_TI_DONE * B + b] = 1; TI[ASLR_TI_ACCEPTED * B + b] = -1; }
     return;
   }
-  // ---- refill: cold start of problem jn in slot b (solve([], [], maxiter): xs = 0, us = 0) ----
+  // ---- refill: problem jn starts in slot b from its initial guess (zeros: solve([], [], maxiter)) ----
   for (int t = tid; t <= T; t += 64) {
     const size_t tb = (size_t)t * B + b;
-    for (int i = 0; i < nx; ++i) { a.xs[tb * nx + i] = 0.0; a.gaps[tb * nx + i] = 0.0; a.vxxf[tb * nx + i] = 0.0; }
+    for (int i = 0; i < nx; ++i) {
+      a.xs[tb * nx + i] = pl.xs_init ? pl.xs_init[((size_t)jn * (T + 1) + t) * nx + i] : 0.0;
+      a.gaps[tb * nx + i] = 0.0; a.vxxf[tb * nx + i] = 0.0;
+    }
     if (t < T)
-      for (int i = 0; i < nu; ++i) { a.us[tb * nu + i] = 0.0; a.kff[tb * nu + i] = 0.0; }
+      for (int i = 0; i < nu; ++i) {
+        a.us[tb * nu + i] = pl.us_init ? pl.us_init[((size_t)jn * T + t) * nu + i] : 0.0;
+        a.kff[tb * nu + i] = 0.0;
+      }
   }
   if (tid < nx) const_cast<double *>(a.x0)[(size_t)b * nx + tid] = pl.x0[(size_t)jn * nx + tid];
   if (tid < 12 && pl.frame_ref && a.frame_ref) const_cast<double *>(a.frame_ref)[12 * (size_t)b + tid] = pl.frame_ref[12 * (size_t)jn + tid];
@@ -748,6 +754,7 @@ int aslr_solve_pool(aslr_problem_t *p, const aslr_solver_params_t *sp, const asl
   PoolDev pl;
   pl.P = pool->P; pl.nx = p->nx; pl.nu = p->nu;
   pl.x0 = pool->x0; pl.frame_ref = pool->frame_ref; pl.xs_out = pool->xs_out; pl.us_out = pool->us_out;
+  pl.xs_init = pool->xs_init; pl.us_init = pool->us_init;
   pl.stat_f = pool->stat_f; pl.stat_i = pool->stat_i; pl.slot_problem = pool->slot_problem; pl.counters = pool->counters;
   const double reg0 = std::isnan(sp->reg_init) ? sp->reg_min : sp->reg_init;
   // every slot starts idle; the first refill hands out the first B problems

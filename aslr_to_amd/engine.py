@@ -251,10 +251,11 @@ class Engine(object):
                        C.c_void_p(du.data_ptr()), C.c_void_p(r.data_ptr()), self._stream())
         return r[:, :nr].cpu().numpy()
 
-    def solve_pool(self, x0s, frame_refs, sp, refill_every=4, poll_every=16):
+    def solve_pool(self, x0s, frame_refs, sp, refill_every=4, poll_every=16, xs_init=None, us_init=None):
         """A pool of P problems of this engine's structure solved through its B slots, each to its own convergence
         (aslr_solve_pool: stopped slots are flushed and refilled on the device; every problem is cold-started).
-        x0s [P, nx], frame_refs [P, 12] or None (host or device).  -> dict of device tensors: xs [P, T+1, nx],
+        x0s [P, nx], frame_refs [P, 12] or None, xs_init [P, T+1, nx] / us_init [P, T, nu] or None = zeros (host or
+        device).  -> dict of device tensors: xs [P, T+1, nx],
         us [P, T, nu], cost / stop / x_reg / step [P], iters / status [P] (int32), and batch_iters (int)."""
         torch = _torch()
         with torch.cuda.device(self.device):
@@ -267,6 +268,15 @@ class Engine(object):
                 fr = torch.as_tensor(frame_refs, dtype=torch.float64, device=self.device).contiguous()
                 if tuple(fr.shape) != (P, 12):
                     raise ValueError("frame_refs must have shape [P, 12]")
+            xi = ui = None
+            if xs_init is not None:
+                xi = torch.as_tensor(xs_init, dtype=torch.float64, device=self.device).contiguous()
+                if tuple(xi.shape) != (P, self.T + 1, self.nx):
+                    raise ValueError("xs_init must have shape [P, T+1, nx]")
+            if us_init is not None:
+                ui = torch.as_tensor(us_init, dtype=torch.float64, device=self.device).contiguous()
+                if tuple(ui.shape) != (P, self.T, self.nu):
+                    raise ValueError("us_init must have shape [P, T, nu]")
             xs = torch.empty((P, self.T + 1, self.nx), dtype=torch.float64, device=self.device)
             us = torch.empty((P, self.T, self.nu), dtype=torch.float64, device=self.device)
             sf = torch.zeros((P, 4), dtype=torch.float64, device=self.device)
@@ -278,6 +288,8 @@ class Engine(object):
         pool.x0, pool.frame_ref = x0.data_ptr(), (fr.data_ptr() if fr is not None else None)
         pool.xs_out, pool.us_out, pool.stat_f, pool.stat_i = xs.data_ptr(), us.data_ptr(), sf.data_ptr(), si.data_ptr()
         pool.slot_problem, pool.counters = slot.data_ptr(), cnt.data_ptr()
+        pool.xs_init = xi.data_ptr() if xi is not None else None
+        pool.us_init = ui.data_ptr() if ui is not None else None
         it = C.c_int32(0)
         self._call("aslr_solve_pool", C.byref(sp), C.byref(pool), int(refill_every), int(poll_every), self._stream(),
                    C.byref(it))

@@ -292,8 +292,10 @@ int aslr_solve(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t poll_e
  * member (BoxDDP at C3: 400 lock-step iterations where a trajectory needs 107 on average).  Here a slot whose problem has
  * stopped (converged, regularisation at its maximum, or sp->maxiter iterations) is flushed to the outputs and refilled
  * with the next problem of the pool every `refill_every` iterations, on the device, so the slots stay busy.
- * Every problem is cold-started (xs = 0, us = 0: `solve([], [], maxiter)`) and goes through exactly the iterations
- * aslr_solve would give it: results do not depend on B, on the slot or on refill_every, bit for bit.
+ * Every problem starts from its own initial guess -- xs_init / us_init, e.g. `[x0] * (T + 1)` and the quasi-static controls
+ * of examples/two_dof_sea.py:77-81, or a cold start (xs = 0, us = 0: `solve([], [], maxiter)`) when they are NULL -- and
+ * goes through exactly the iterations aslr_solve would give it: results do not depend on B, on the slot or on
+ * refill_every, bit for bit.
  * All pointers are DEVICE pointers owned by the caller. */
 typedef struct aslr_pool {
   int32_t P;                  /* problems in the pool                                                          */
@@ -307,6 +309,8 @@ typedef struct aslr_pool {
   int32_t *stat_i;            /* [P][2]: iterations, ASLR_ST_* status word                                     */
   int32_t *slot_problem;      /* [B] scratch: the problem in each slot (-1: idle)                              */
   int32_t *counters;          /* [2] scratch: next problem to hand out, problems finished                      */
+  const double *xs_init;      /* [P][T+1][nx] initial guesses (batch-major), or NULL: zeros                     */
+  const double *us_init;      /* [P][T][nu], or NULL: zeros                                                    */
 } aslr_pool_t;
 /* `iters_done` (host, optional) receives the lock-step iterations launched.  The host polls the finished-problem
  * counter every `poll_every` iterations (one 4-byte D2H). */

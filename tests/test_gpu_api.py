@@ -586,6 +586,16 @@ def test_pool_solve_gives_every_problem_the_solve_it_would_get_in_a_batch():
         assert torch.equal(r["cost"], cost)
         waves = -(-P // 64)
         assert r["batch_iters"] < waves * int(iters.max())
+    # warm-started pool (per-problem initial guesses) against the same warm start as one batch
+    rng = np.random.default_rng(3)
+    xs0 = np.repeat(sc["x0"][:, None, :], T + 1, axis=1) + 1e-2 * rng.standard_normal((P, T + 1, 8))
+    us0 = np.abs(1e-1 * rng.standard_normal((P, T, 4)))
+    full.set_candidate(xs0, us0)
+    full.solve(sp, poll_every=8)
+    torch.cuda.synchronize()
+    rw = e.solve_pool(sc["x0"], sc["frame_refs"], sp, refill_every=3, poll_every=9, xs_init=xs0, us_init=us0)
+    assert torch.equal(rw["xs"], full.region(_abi.R_XS).permute(1, 0, 2).contiguous())
+    assert torch.equal(rw["iters"], full.traj_i(_abi.TI_ITER))
     # a pool smaller than the slots, and a solver without bounds on the same engine afterwards
     r = e.solve_pool(sc["x0"][:10], sc["frame_refs"][:10], sp)
     assert torch.equal(r["xs"], X[:10]) and torch.equal(r["iters"], iters[:10])
