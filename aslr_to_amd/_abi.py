@@ -219,7 +219,7 @@ def load_library():
     lib.aslr_set_iteration_log.argtypes = [vp, vp, i32]
     if lib.aslr_abi_version() != ABI_VERSION:
         raise ImportError("aslr_to_amd: ABI version mismatch between %s and the Python layer" % path)
-    for which, st in enumerate((Chain, Cost, Model, ProblemDesc, SolverParams, Region)):
+    for which, st in enumerate((Chain, Cost, Model, ProblemDesc, SolverParams, Region, Pool)):
         if lib.aslr_sizeof(which) != C.sizeof(st):
             raise ImportError("aslr_to_amd: struct %s size mismatch (C %d, Python %d)"
                               % (st.__name__, lib.aslr_sizeof(which), C.sizeof(st)))

@@ -398,6 +398,7 @@ int64_t aslr_sizeof(int which) {
   case 3: return sizeof(aslr_problem_desc_t);
   case 4: return sizeof(aslr_solver_params_t);
   case 5: return sizeof(aslr_region_t);
+  case 6: return sizeof(aslr_pool_t);
   default: return -1;
   }
 }

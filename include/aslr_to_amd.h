@@ -243,7 +243,7 @@ typedef struct aslr_problem aslr_problem_t; /* opaque */
 /* ---- ABI self-description (callable without a GPU) ------------------------------------ */
 int aslr_abi_version(void);
 /* sizeof() of the POD structs above as compiled, so a binding can check its mirror:
- * which = 0 chain, 1 cost, 2 model, 3 problem_desc, 4 solver_params, 5 region */
+ * which = 0 chain, 1 cost, 2 model, 3 problem_desc, 4 solver_params, 5 region, 6 pool */
 int64_t aslr_sizeof(int which);
 /* record length in doubles (padded) for given nx, nu */
 int32_t aslr_record_len(int32_t nx, int32_t nu);
