@@ -14,6 +14,7 @@
 #pragma once
 #include <utility>
 #include "aslr_common.hpp"
+#include "aslr_team_ops.hpp"
 
 namespace aslr {
 
@@ -181,14 +182,17 @@ struct BwdCfg {
   // this knot's record has been consumed, so no prefetch registers stay live across the gains / box-QP phase.
   // One instruction covers a block of BS doubles of each team's record: element e of team tm sits at
   // (e / BS) * DMAW + tm * BS + e % BS.
-  static constexpr bool DMA = (NX == 8 && HS == 2 && TPW == 4 && NU % 2 == 0);
+  static constexpr bool DMA = (NX == 8 && HS >= 2 && TPW == 64 / TEAM && NU % 2 == 0);
+  // nu = 4 gains and box QP spread over the lanes of a 16-lane DPP row (aslr_team_gains.hpp) instead of every lane
+  // running the whole 4x4 problem on register arrays
+  static constexpr bool TEAMQP = DMA && NU == 4 && TEAM % 16 == 0;
   static constexpr int BS = 2 * TEAM, DMAW = 128;
   static constexpr int AUXL = NU + NX / 2; // lanes of a team that fetch the small inputs
   static constexpr int ridx(int e) { return (e / BS) * DMAW + e % BS; }
   // every (constant + per-lane offset) access of the kernel must stay inside one block
   static constexpr bool in_block(int cst, int rtmax) { return cst % BS + rtmax < BS; }
   static constexpr bool dma_layout_ok() {
-    bool ok = (RPL * NX == BS) && (REC % 2 == 0) && (AUXL <= TEAM);
+    bool ok = (REC % 2 == 0) && (AUXL <= TEAM); // (the Lxx rows are read through per-lane offsets: lxx_idx)
     for (int l = 0; l < NX; ++l) {
       for (int i = 0; i < RPL; ++i) ok = ok && in_block(oFx + l * NX + i, (HS - 1) * RPL);
       for (int c = 0; c < NUH; ++c) ok = ok && in_block(oFu + l * NU + c, (HS - 1) * NUH);
@@ -213,7 +217,7 @@ ASLR_DEV void dma_record(const char *g, unsigned recD_addr, int lt, std::integer
 // BOX: SolverBoxDDP gains may be needed (solver is BoxDDP); GAPS: infeasible candidates may be present
 // (gap terms, FDDP expected-improvement terms).  A wave whose trajectories need neither runs the lean variant.
 #ifndef ASLR_BWD_WAVES
-#define ASLR_BWD_WAVES 1 // (experiments: waves per SIMD the HS = 4 variant must fit)
+#define ASLR_BWD_WAVES 2 // waves per SIMD the HS = 4 variant (two 32-lane teams per wave) must fit
 #endif
 template <int NX, int NU, int HS, int TPWA, bool BOX, bool GAPS>
 __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
@@ -283,6 +287,28 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
   ASLR_UNROLL for (int c = 0; c < NUH; ++c) oh_u0[c] = (c0 + c == j) ? 1.0 : 0.0;
   ASLR_UNROLL for (int i = 0; i < RPL; ++i) oh_row[i] = (r0 + i == jj) ? 1.0 : 0.0;
   ASLR_UNROLL for (int c = 0; c < NU; ++c) oh_u[c] = (c == j) ? 1.0 : 0.0;
+
+  // LDS index of Lxx(r0 + i, jj) inside this team's DMA blocks
+  int lxx_idx[RPL];
+  ASLR_UNROLL for (int i = 0; i < RPL; ++i) {
+    const int e = C::oLxx + (r0 + i) * NX + jj;
+    lxx_idx[i] = C::DMA ? (e / C::BS) * C::DMAW + e % C::BS : 0;
+  }
+  // team-distributed gains (nu = 4): this lane is row qr of the 4x4 problem; control limits of every model in LDS so
+  // that a lane reads ITS bound with one load ([model][lb 0..3 | ub 0..3])
+  const int qr = lt & 3;
+  double oh4[4];
+  ASLR_UNROLL for (int c = 0; c < 4; ++c) oh4[c] = (c == qr) ? 1.0 : 0.0;
+  __shared__ double limL[C::TEAMQP && BOX ? ASLR_MAX_MODELS * 8 : 1];
+  if (C::TEAMQP && BOX) {
+    ASLR_UNROLL for (int m = 0; m < ASLR_MAX_MODELS; ++m)
+      ASLR_UNROLL for (int c = 0; c < 4; ++c) {
+        limL[m * 8 + c] = lim.lb[m][c]; // (every lane writes the same values)
+        limL[m * 8 + 4 + c] = lim.ub[m][c];
+      }
+    wave_sync();
+  }
+  const TeamQPParams qpp{sp.boxqp_maxiter, sp.boxqp_th_acceptstep, sp.boxqp_th_grad, sp.boxqp_reg, ASLR_NALPHA};
 
   double d1 = 0.0, d2 = 0.0, stop = 0.0, dgf = 0.0, dqf = 0.0;
   ASLR_PROF_DECL;
@@ -421,7 +447,7 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
             accq[c] += bt * Fucol[l];
           }
         }
-        ASLR_UNROLL for (int i = 0; i < RPL; ++i) Qxx[i] = (C::DMA ? recT[C::ridx(C::oLxx + i * NX) + jj + h * C::DMAW] : rec[C::oLxx + row(i) * NX + jj]) + acc[i];
+        ASLR_UNROLL for (int i = 0; i < RPL; ++i) Qxx[i] = (C::DMA ? recT[lxx_idx[i]] : rec[C::oLxx + row(i) * NX + jj]) + acc[i];
         ASLR_UNROLL for (int c = 0; c < NUH; ++c) QuxL[(c0 + c) * NX + jj] = R(C::oLxu + c, jj * NU + c0) + accu[c];
         if (j < NU) {
           ASLR_UNROLL for (int c = 0; c < NUH; ++c)
@@ -441,8 +467,57 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
         if (t > 0) ASLR_BWD_DMA(t - 1);
       }
       ASLR_PROF(3);
-      // ---- step 3: gains (redundant per lane) ----
-      double Quu[NU][NU], qu[NU], kv[NU], Kc[NU];
+      // ---- step 3: gains ----
+      double Kc[NU];
+      double kj_out = 0.0, qj_out = 0.0; // this lane's entries of k and Qu (lanes j < NU of the writer set)
+      if constexpr (C::TEAMQP) {
+        // one entry of every 4-vector and one row of Quu per lane; broadcasts through DPP (aslr_team_gains.hpp)
+        double Hr[4];
+        {
+          const double2 h01 = *reinterpret_cast<const double2 *>(QuuL + qr * NU), h23 = *reinterpret_cast<const double2 *>(QuuL + qr * NU + 2);
+          Hr[0] = h01.x; Hr[1] = h01.y; Hr[2] = h23.x; Hr[3] = h23.y;
+        }
+        const double q_own = QuL[qr];
+        const bool boxed = box && lim.has[mi];
+        double lbr = 0.0, ubr = 0.0, k0r = 0.0;
+        if (BOX) {
+          const double utr = auxT[qr];
+          k0r = auxT[NU + qr];
+          lbr = limL[mi * 8 + qr] - utr;
+          ubr = limL[mi * 8 + 4 + qr] - utr;
+        }
+        ASLR_PROF(4);
+        TeamFactor<DevTeamOps> F;
+        double kv_own, qz_own;
+        bool gbad;
+        team_gains4<DevTeamOps, BOX>(Hr, q_own, boxed, lbr, ubr, k0r, oh4, qpp, kv_own, qz_own, F, gbad);
+        if (gbad) failed = true;
+        ASLR_PROF(5);
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) Kc[c] = Qux[c];
+        team_gain_column<DevTeamOps>(F, Kc);
+        ASLR_PROF(16);
+        // Quu k (row qr), expected-improvement terms, Vx
+        double Quuk = 0.0;
+        DevTeamOps::matvec_acc<false>(Quuk, kv_own, Hr);
+        {
+          const double one = 1.0, t1 = qz_own * kv_own, t2 = kv_own * Quuk, t3 = qz_own * qz_own;
+          DevTeamOps::fmac_bc<0, false>(d1, t1, one); DevTeamOps::fmac_bc<1, false>(d1, t1, one);
+          DevTeamOps::fmac_bc<2, false>(d1, t1, one); DevTeamOps::fmac_bc<3, false>(d1, t1, one);
+          DevTeamOps::fmac_bc<0, true>(d2, t2, one); DevTeamOps::fmac_bc<1, true>(d2, t2, one);
+          DevTeamOps::fmac_bc<2, true>(d2, t2, one); DevTeamOps::fmac_bc<3, true>(d2, t2, one);
+          DevTeamOps::fmac_bc<0, false>(stop, t3, one); DevTeamOps::fmac_bc<1, false>(stop, t3, one);
+          DevTeamOps::fmac_bc<2, false>(stop, t3, one); DevTeamOps::fmac_bc<3, false>(stop, t3, one);
+        }
+        {
+          double s = 0.0, s2 = 0.0;
+          DevTeamOps::matvec_acc<false>(s, Quuk, Kc);
+          DevTeamOps::matvec_acc<false>(s2, qz_own, Kc);
+          Vx_own = Qx + s - 2.0 * s2;
+        }
+        kj_out = kv_own; // (lanes j < 4 have qr = j)
+        qj_out = qz_own;
+      } else {
+      double Quu[NU][NU], qu[NU], kv[NU];
       ASLR_UNROLL for (int c = 0; c < NU; ++c) {
         qu[c] = QuL[c];
         ASLR_UNROLL for (int e = 0; e < NU; ++e) Quu[c][e] = QuuL[c * NU + e];
@@ -539,6 +614,10 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
         ASLR_UNROLL for (int c = 0; c < NU; ++c) { s += Kc[c] * Quuk[c]; s2 += Kc[c] * qu[c]; }
         Vx_own = Qx + s - 2.0 * s2;
       }
+        if (j < NU) {
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) { kj_out += oh_u[c] * kv[c]; qj_out += oh_u[c] * qu[c]; }
+        }
+      }
       {
         double acc[RPL];
         ASLR_UNROLL for (int i = 0; i < RPL; ++i) acc[i] = 0.0;
@@ -554,10 +633,8 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
         double *Kout = a.kgain + tb * NU * NX;
         ASLR_UNROLL for (int c = 0; c < NU; ++c) Kout[c * NX + jj] = Kc[c];
         if (j < NU) {
-          double kj = 0.0, qj = 0.0;
-          ASLR_UNROLL for (int c = 0; c < NU; ++c) { kj += oh_u[c] * kv[c]; qj += oh_u[c] * qu[c]; }
-          a.kff[tb * NU + j] = kj;
-          a.qu[tb * NU + j] = qj;
+          a.kff[tb * NU + j] = kj_out;
+          a.qu[tb * NU + j] = qj_out;
         }
       }
       wave_sync();
@@ -569,6 +646,9 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
         chk += fabs(Pcol[r]);
       }
       if (gaps_on) {
+        if (C::TEAMQP) { // (the gap of this knot is still in its aux slot: the next DMA writes the other one)
+          ASLR_UNROLL for (int r = 0; r < NX; ++r) fg[r] = auxT[2 * NU + r];
+        }
         double vf = 0.0;
         ASLR_UNROLL for (int r = 0; r < NX; ++r) vf += Pcol[r] * fg[r];
         Vx_own += vf;

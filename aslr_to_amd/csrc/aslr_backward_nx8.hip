@@ -6,9 +6,7 @@ int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, con
   if (hs == 0) hs = k.B <= 8192 ? 2 : 1; // wider teams when the batch cannot fill the chip
   if (nu == 2) return hs == 2 ? launch_backward_t<8, 2, 2>(k, sd, lim, all_feasible, st) : launch_backward_t<8, 2, 1>(k, sd, lim, all_feasible, st);
   if (nu == 4) {
-#ifdef ASLR_BWD_HS4
     if (hs == 4) return launch_backward_t<8, 4, 4>(k, sd, lim, all_feasible, st);
-#endif
     return hs == 2 ? launch_backward_t<8, 4, 2>(k, sd, lim, all_feasible, st) : launch_backward_t<8, 4, 1>(k, sd, lim, all_feasible, st);
   }
   snprintf(err_buf(), kErrLen, "backward: unsupported (nx=8, nu=%d)", nu);

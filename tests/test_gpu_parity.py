@@ -93,7 +93,7 @@ def _backward_inputs(oracle, low, seed):
 
 @pytest.mark.parametrize("name,kw", CASES)
 @pytest.mark.parametrize("feasible", [0, 1])
-@pytest.mark.parametrize("hs", [0, 1, 2])
+@pytest.mark.parametrize("hs", [0, 1, 2, 4])
 def test_backward_pass_matches_oracle(oracle, monkeypatch, name, kw, feasible, hs):
     import torch
     if hs:   # 0: the default decomposition of the size (block-per-trajectory LDS kernel at nx = 28)

@@ -27,10 +27,11 @@ torch.cuda.synchronize()
 lib.aslr_debug_bwd_prof(out, 0)
 v = np.array(list(out), dtype=np.float64)
 knots = v[15]
-names = ["top: wait for the record", "step 1", "step 2", "DMA issue", "step 3 (first active set)", "plain gains",
+# (nu = 4 runs the team-distributed gains of aslr_team_gains.hpp: regions 6-9 of the per-lane QP stay empty there)
+names = ["top: wait for the record", "step 1", "step 2", "DMA issue", "gains inputs (Quu row, bounds) / first active set", "team gains: factor, Newton point, QP / plain gains",
          "box decision + QP prologue", "QP head (mask, factor, solve)", "QP line search + gradient", "QP final gains",
-         "tail (Vx, Vxx, stores)", "step 4 + loop"]
-names.append("after the box branch (incl. waiting for wave mates' QP)")
+         "tail (Quu k, Vx, Vxx, stores)", "step 4 + loop"]
+names.append("gain column K / after the box branch")
 v = np.concatenate([v[:12], v[16:17], v[12:16]])
 tot = v[:13].sum()
 v = np.concatenate([v[:13], np.zeros(3), v[13:]])
