@@ -242,9 +242,10 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
   double *sm = smem + (team < TPW ? team : 0) * C::LDS_TEAM;
   double *rec = sm + C::sRec, *AT = sm + C::sAT, *BT = sm + C::sBT, *QuxL = sm + C::sQux, *VT = sm + C::sVT,
          *QuuL = sm + C::sQuu, *QuL = sm + C::sQu, *VxL = sm + C::sVx;
-  __shared__ __attribute__((aligned(16))) double recD[C::DMA ? C::NPRE * C::DMAW : 2];
+  // two record buffers (by parity of the knot): the DMA of knot t - 1 is issued at the TOP of knot t, a whole knot ahead
+  __shared__ __attribute__((aligned(16))) double recD[C::DMA ? 2 * C::NPRE * C::DMAW : 2];
   __shared__ __attribute__((aligned(16))) double auxD[C::DMA ? 2 * C::DMAW : 2];
-  const double *recT = recD + (C::DMA ? team * C::BS : 0);
+  const double *recT = recD + (C::DMA ? team * C::BS : 0); // (re-pointed to the knot's buffer at the top of every knot)
   // record element (compile-time part cst, per-lane part rt)
   auto R = [&](int cst, int rt) -> double { return C::DMA ? recT[C::ridx(cst) + rt] : rec[cst + rt]; };
   auto row = [&](int i) { return C::EXACT ? r0 + i : (r0 + i < NX ? r0 + i : NX - 1); };
@@ -312,6 +313,9 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
 
   double d1 = 0.0, d2 = 0.0, stop = 0.0, dgf = 0.0, dqf = 0.0;
   ASLR_PROF_DECL;
+#ifdef ASLR_BWD_PROFILE
+  if (C::TEAMQP && threadIdx.x == 0) { for (int i = 0; i < 16; ++i) tg_prof()[i] = 0; }
+#endif
   while (__ballot(need) != 0ull) {
     bool failed = false;
     d1 = d2 = stop = dgf = dqf = 0.0;
@@ -338,10 +342,12 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
         double *o = a.vxx + ((size_t)T * B + b) * NX * NX;
         ASLR_UNROLL for (int r = 0; r < NX; ++r) o[r * NX + jj] = Pcol[r];
       }
-      wave_sync();
-      VxL[jj] = Vx_own;
-      wave_sync();
-      ASLR_UNROLL for (int l = 0; l < NX; ++l) pvec[l] = VxL[l];
+      if (!C::TEAMQP) { // (there Vx stays spread over lanes 0..7 of the row and reaches the products through DPP)
+        wave_sync();
+        VxL[jj] = Vx_own;
+        wave_sync();
+        ASLR_UNROLL for (int l = 0; l < NX; ++l) pvec[l] = VxL[l];
+      }
     }
     // ---- prefetch for knot T-1: record, model index, box-QP inputs, gap ----
     double prx[C::NPRE], pry[C::NPRE];
@@ -371,7 +377,7 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
 #define ASLR_BWD_DMA(tt)                                                                               \
     do {                                                                                               \
       const char *kb = reinterpret_cast<const char *>(a.deriv + (size_t)(tt) * B * REC); /* uniform */ \
-      dma_record<C>(kb + rec_voff, lds_address(recD), lt, std::make_integer_sequence<int, C::NPRE>()); \
+      dma_record<C>(kb + rec_voff, lds_address(recD) + ((tt) & 1) * (C::NPRE * C::DMAW * 8), lt, std::make_integer_sequence<int, C::NPRE>()); \
       if (aux_on) dma16<0>(reinterpret_cast<const char *>(aux_src + (size_t)(tt) * aux_step), lds_address(auxD) + ((tt) & 1) * C::DMAW * 8); \
       pre_m = node_model_at(a, tt);                                                                        \
     } while (0)
@@ -382,6 +388,32 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
     const double *aux_src = (lt < NU / 2 ? a.us + 2 * lt : (lt < NU ? a.kff + 2 * (lt - NU / 2) : a.gaps + 2 * (lt - NU))) + (size_t)b * aux_stride;
     const size_t aux_step = (size_t)B * aux_stride; // doubles per knot
     const bool aux_on = lt < NU ? box : (gaps_on && lt < C::AUXL);
+    // results of a knot: K / k / Qu (state of the gains phase), Vx / Vxx / Vxx f (state after step 4).  In the DMA
+    // configurations they are issued at the top of the NEXT knot of the sweep (and after the last one).
+    bool st_k = false, st_v = false, st_f = false;
+    double Kc_st[NU], kj_st = 0.0, qj_st = 0.0, vf_st = 0.0;
+    ASLR_UNROLL for (int c = 0; c < NU; ++c) Kc_st[c] = 0.0;
+#define ASLR_BWD_STORES_K(tbs)                                                                         \
+    do {                                                                                               \
+      if (st_k) {                                                                                      \
+        double *Kout = a.kgain + (tbs) * NU * NX;                                                      \
+        ASLR_UNROLL for (int c = 0; c < NU; ++c) Kout[c * NX + jj] = Kc_st[c];                         \
+        if (j < NU) {                                                                                  \
+          a.kff[(tbs) * NU + j] = kj_st;                                                               \
+          a.qu[(tbs) * NU + j] = qj_st;                                                                \
+        }                                                                                              \
+      }                                                                                                \
+    } while (0)
+#define ASLR_BWD_STORES_V(tbs)                                                                         \
+    do {                                                                                               \
+      if (st_f) a.vxxf[(tbs) * NX + jj] = vf_st;                                                       \
+      if (st_v) {                                                                                      \
+        a.vx[(tbs) * NX + jj] = Vx_own;                                                                \
+        double *o = a.vxx + (tbs) * NX * NX;                                                           \
+        ASLR_UNROLL for (int r = 0; r < NX; ++r) o[r * NX + jj] = Pcol[r];                             \
+      }                                                                                                \
+    } while (0)
+#define ASLR_BWD_STORES(tbs) do { ASLR_BWD_STORES_K(tbs); ASLR_BWD_STORES_V(tbs); } while (0)
     if (C::DMA) ASLR_BWD_DMA(T - 1); else ASLR_BWD_PREFETCH(T - 1);
     for (int t = T - 1; t >= 0; --t) {
       const size_t tb = (size_t)t * B + b;
@@ -389,10 +421,16 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
       ASLR_PROF_COUNT(15);
       const double *auxT = auxD + (C::DMA ? (t & 1) * C::DMAW + team * C::BS : 0); // [us | k | gap] of this knot
       double ut[NU], k0[NU], fg[NX];
+      const int mi = pre_m; // (before the next knot's loads are issued: they fetch ITS model index into pre_m)
       if (C::DMA) {
-        // the record of this knot (issued during the previous one) has landed
+        // the record of this knot (issued at the top of the previous one) has landed, and the stores issued there are done
         wait_vmcnt<0>();
         wave_sync();
+        recT = recD + (t & 1) * (C::NPRE * C::DMAW) + team * C::BS;
+        // results of knot t + 1, then the loads of knot t - 1: every vector-memory operation of the sweep gets a whole
+        // knot before anything waits for it
+        ASLR_BWD_STORES(tb + B);
+        if (t > 0) ASLR_BWD_DMA(t - 1);
       } else {
         // stage the record in LDS, take this knot's small inputs, start the next loads
         double2 *dst = reinterpret_cast<double2 *>(rec);
@@ -403,7 +441,6 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
         ASLR_UNROLL for (int c = 0; c < NU; ++c) { ut[c] = pre_u[c]; k0[c] = pre_k[c]; }
         ASLR_UNROLL for (int r = 0; r < NX; ++r) fg[r] = pre_f[r];
       }
-      const int mi = pre_m;
       if (!C::DMA) {
         wave_sync();
         if (t > 0) ASLR_BWD_PREFETCH(t - 1);
@@ -427,7 +464,12 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
       double Qx, Qu_own;
       {
         double s = 0.0, s2 = 0.0;
-        ASLR_UNROLL for (int l = 0; l < NX; ++l) { s += Fxcol[l] * pvec[l]; s2 += Fucol[l] * pvec[l]; }
+        if constexpr (C::TEAMQP) {
+          DevTeamOps::dot8_acc(s, Vx_own, Fxcol); // lane l of the row holds Vx[l]
+          DevTeamOps::dot8_acc(s2, Vx_own, Fucol);
+        } else {
+          ASLR_UNROLL for (int l = 0; l < NX; ++l) { s += Fxcol[l] * pvec[l]; s2 += Fucol[l] * pvec[l]; }
+        }
         Qx = R(C::oLx, jj) + s;
         Qu_own = R(C::oLu, ju) + s2;
       }
@@ -458,13 +500,8 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
       wave_sync();
       ASLR_UNROLL for (int c = 0; c < NU; ++c) Qux[c] = QuxL[c * NX + jj];
       ASLR_PROF(2);
-      if (C::DMA) {
-        // this knot's record is consumed: take the control inputs, then let the next knot's loads fly
-        // under the gains phase
+      if (C::DMA && !C::TEAMQP) {
         ASLR_UNROLL for (int c = 0; c < NU; ++c) { ut[c] = auxT[c]; k0[c] = auxT[NU + c]; } // (used by box nodes only)
-        wait_lgkmcnt0(); // every LDS read of the record has returned
-        wave_sync();
-        if (t > 0) ASLR_BWD_DMA(t - 1);
       }
       ASLR_PROF(3);
       // ---- step 3: gains ----
@@ -501,12 +538,7 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
         DevTeamOps::matvec_acc<false>(Quuk, kv_own, Hr);
         {
           const double one = 1.0, t1 = qz_own * kv_own, t2 = kv_own * Quuk, t3 = qz_own * qz_own;
-          DevTeamOps::fmac_bc<0, false>(d1, t1, one); DevTeamOps::fmac_bc<1, false>(d1, t1, one);
-          DevTeamOps::fmac_bc<2, false>(d1, t1, one); DevTeamOps::fmac_bc<3, false>(d1, t1, one);
-          DevTeamOps::fmac_bc<0, true>(d2, t2, one); DevTeamOps::fmac_bc<1, true>(d2, t2, one);
-          DevTeamOps::fmac_bc<2, true>(d2, t2, one); DevTeamOps::fmac_bc<3, true>(d2, t2, one);
-          DevTeamOps::fmac_bc<0, false>(stop, t3, one); DevTeamOps::fmac_bc<1, false>(stop, t3, one);
-          DevTeamOps::fmac_bc<2, false>(stop, t3, one); DevTeamOps::fmac_bc<3, false>(stop, t3, one);
+          DevTeamOps::acc3(d1, t1, d2, t2, stop, t3, one);
         }
         {
           double s = 0.0, s2 = 0.0;
@@ -629,14 +661,10 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
           if (row_ok(i)) VT[jj * NX + r0 + i] = (Qxx[i] - acc[i]) + oh_row[i] * xr;
       }
       const bool st_ok = writer && need && !failed;
-      if (st_ok) {
-        double *Kout = a.kgain + tb * NU * NX;
-        ASLR_UNROLL for (int c = 0; c < NU; ++c) Kout[c * NX + jj] = Kc[c];
-        if (j < NU) {
-          a.kff[tb * NU + j] = kj_out;
-          a.qu[tb * NU + j] = qj_out;
-        }
-      }
+      st_k = st_ok;
+      ASLR_UNROLL for (int c = 0; c < NU; ++c) Kc_st[c] = Kc[c];
+      kj_st = kj_out; qj_st = qj_out;
+      if (!C::DMA) ASLR_BWD_STORES_K(tb);
       wave_sync();
       ASLR_PROF(10);
       // ---- step 4: symmetrise (column jj of the symmetric Vxx = its row jj), gap term, publish Vx ----
@@ -657,7 +685,7 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
           ASLR_UNROLL for (int r = 1; r < NX; ++r) if (r == jj) fj = fg[r];
           dgf -= Vx_own * fj;
           dqf += fj * vf;
-          if (st_ok) a.vxxf[tb * NX + jj] = vf;
+          vf_st = vf;
         }
       }
       chk += fabs(Vx_own);
@@ -669,15 +697,16 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
         ent[NX] = Vx_own;
         if (__ballot(inf_norm_bad<NX + 1>(chk, ent)) & team_mask) failed = true;
       }
-      if (sp.store_v && st_ok && !failed) {
-        a.vx[tb * NX + jj] = Vx_own;
-        double *o = a.vxx + tb * NX * NX;
-        ASLR_UNROLL for (int r = 0; r < NX; ++r) o[r * NX + jj] = Pcol[r];
+      st_v = sp.store_v && st_ok && !failed;
+      st_f = gaps_on && fddp && st_ok;
+      if (!C::DMA) ASLR_BWD_STORES_V(tb);
+      if (!C::TEAMQP) {
+        VxL[jj] = Vx_own;
+        wave_sync();
+        ASLR_UNROLL for (int l = 0; l < NX; ++l) pvec[l] = VxL[l];
       }
-      VxL[jj] = Vx_own;
-      wave_sync();
-      ASLR_UNROLL for (int l = 0; l < NX; ++l) pvec[l] = VxL[l];
     }
+    if (C::DMA) ASLR_BWD_STORES((size_t)b); // knot 0
     ASLR_PROF(11);
     // ---- end of sweep: publish or regularise and retry ----
     if (need) {
@@ -722,6 +751,13 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_k
       }
     }
   }
+#ifdef ASLR_BWD_PROFILE
+  if (C::TEAMQP && threadIdx.x == 0) { // team-gains regions 1..5 -> table entries 6..9 (+ 5 stays the total), counters 10..12 -> 13, 12, 14
+    long long *g = tg_prof();
+    prof_acc[6] += g[1]; prof_acc[7] += g[2]; prof_acc[8] += g[3]; prof_acc[9] += g[4] + g[5];
+    prof_acc[13] += g[10]; prof_acc[12] += g[11]; prof_acc[14] += g[12];
+  }
+#endif
   ASLR_PROF_FLUSH;
 }
 

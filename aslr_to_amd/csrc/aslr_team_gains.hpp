@@ -22,6 +22,10 @@
 #ifndef ASLR_TG_FN
 #define ASLR_TG_FN inline
 #endif
+#ifndef ASLR_TG_MARK
+#define ASLR_TG_MARK(i)  // region-timing hook of the profile build (aslr_team_ops.hpp)
+#define ASLR_TG_COUNT(i)
+#endif
 #if defined(__clang__)
 #define ASLR_TG_UNROLL _Pragma("unroll")
 #else
@@ -55,8 +59,7 @@ ASLR_TG_FN typename O::mask team_factor(TeamFactor<O> &F, const typename O::real
   using mask = typename O::mask;
   const real one = O::cst(1.0);
   F.mkL = mk;
-  F.mkk[0] = O::template bc<0>(mk); F.mkk[1] = O::template bc<1>(mk);
-  F.mkk[2] = O::template bc<2>(mk); F.mkk[3] = O::template bc<3>(mk);
+  O::bc4(mk, F.mkk); // mkk[c] = mk of row c
   const real dterm = mk * reg + (one - mk);
   ASLR_TG_UNROLL for (int c = 0; c < 4; ++c) F.Lr[c] = (mk * F.mkk[c]) * Hr[c] + oh[c] * dterm;
   mask bad = O::mfalse();
@@ -80,14 +83,7 @@ ASLR_TG_FN typename O::mask team_factor(TeamFactor<O> &F, const typename O::real
 #undef ASLR_TG_SUB
 #undef ASLR_TG_COL
   // transpose of the strictly lower part: Lc[k] = L[k][r] = sum_c oh[c] * (L[k][c] from lane k), exact
-  F.Lc[0] = O::cst(0.0);
-  F.Lc[1] = O::cst(0.0); F.Lc[2] = O::cst(0.0); F.Lc[3] = O::cst(0.0);
-  O::template fmac_bc<1, false>(F.Lc[1], F.Lr[0], oh[0]);
-  O::template fmac_bc<2, false>(F.Lc[2], F.Lr[0], oh[0]);
-  O::template fmac_bc<2, false>(F.Lc[2], F.Lr[1], oh[1]);
-  O::template fmac_bc<3, false>(F.Lc[3], F.Lr[0], oh[0]);
-  O::template fmac_bc<3, false>(F.Lc[3], F.Lr[1], oh[1]);
-  O::template fmac_bc<3, false>(F.Lc[3], F.Lr[2], oh[2]);
+  O::transpose_lower(F.Lr, oh, F.Lc);
   return bad;
 }
 
@@ -132,11 +128,7 @@ ASLR_TG_FN typename O::real team_solve(const TeamFactor<O> &F, typename O::real 
 // sum of the four elements of a distributed vector, in element order, the same in every lane
 template <class O>
 ASLR_TG_FN typename O::real team_sum(typename O::real t, typename O::real one) {
-  typename O::real s = O::template bc<0>(t);
-  O::template fmac_bc<1, false>(s, t, one);
-  O::template fmac_bc<2, false>(s, t, one);
-  O::template fmac_bc<3, false>(s, t, one);
-  return s;
+  return O::sum4(t, one);
 }
 
 // Gains of one knot.  In (per lane, r = lane & 3): Hr = row r of Quu (regularised), q = Qu_r, `boxed` (the same in
@@ -168,7 +160,9 @@ ASLR_TG_FN void team_gains4(const typename O::real (&Hr)[4], typename O::real q,
   const real reg = BOX ? O::sel(boxed, O::cst(P.reg), zero) : zero;
   mask allcl = O::mfalse();
   if (BOX) allcl = O::team_all(cl);
+  ASLR_TG_MARK(0);
   mask cbad = team_factor<O>(F, Hr, mk, reg, oh);
+  ASLR_TG_MARK(1);
   bad = cbad & (!allcl); // (a factor of a non-empty free block is needed in every outcome)
   real z;
   {
@@ -188,7 +182,9 @@ ASLR_TG_FN void team_gains4(const typename O::real (&Hr)[4], typename O::real q,
   } else {
     x = z;
   }
+  ASLR_TG_MARK(2);
   if (BOX && O::wave_any(!finished)) {
+    ASLR_TG_COUNT(10);
     // f(x) = 1/2 x^T H x + q^T x
     real fold;
     {
@@ -197,6 +193,7 @@ ASLR_TG_FN void team_gains4(const typename O::real (&Hr)[4], typename O::real q,
       fold = team_sum<O>(O::cst(0.5) * x * s + q * x, one);
     }
     for (int it = 0;;) {
+      ASLR_TG_COUNT(11);
       // ---- line search along the projected Newton direction ----
       const real dx = mk * (z - x);
       mask found = finished | cbad;
@@ -219,6 +216,7 @@ ASLR_TG_FN void team_gains4(const typename O::real (&Hr)[4], typename O::real q,
       finished = finished | cbad | (!found);
       g = q;
       O::template matvec_acc<false>(g, x, Hr);
+      ASLR_TG_MARK(3);
       if (++it >= P.maxiter) break;
       // ---- next iteration: active set, convergence, factor, Newton point ----
       cl = ((x == lb) & (g > zero)) | ((x == ub) & (g < zero));
@@ -235,14 +233,18 @@ ASLR_TG_FN void team_gains4(const typename O::real (&Hr)[4], typename O::real q,
         O::template matvec_acc<true>(s, xc, Hr);
         z = team_solve<O>(F, mk * s, oh);
       }
+      ASLR_TG_MARK(4);
     }
+    ASLR_TG_MARK(4);
     // factor of the final free block: the one at hand unless the active set changed in the last step
     const mask stale = O::team_any(!(F.mkL == mk));
     if (O::wave_any(stale)) {
+      ASLR_TG_COUNT(12);
       const mask cb = team_factor<O>(F, Hr, mk, reg, oh);
       bad = bad | (cb & O::team_any(mk > zero));
     }
   }
+  ASLR_TG_MARK(5);
   kv = -x;
   qz = q * mk; // (mk = 0 on clamped entries of boxed nodes, 1 otherwise; exact)
 }
@@ -252,9 +254,8 @@ ASLR_TG_FN void team_gains4(const typename O::real (&Hr)[4], typename O::real q,
 template <class O>
 ASLR_TG_FN void team_gain_column(const TeamFactor<O> &F, typename O::real (&col)[4]) {
   using real = typename O::real;
-  real L10 = O::template bc<1>(F.Lr[0]);
-  real L20 = O::template bc<2>(F.Lr[0]), L21 = O::template bc<2>(F.Lr[1]);
-  real L30 = O::template bc<3>(F.Lr[0]), L31 = O::template bc<3>(F.Lr[1]), L32 = O::template bc<3>(F.Lr[2]);
+  real L10, L20, L21, L30, L31, L32; // the strictly lower part of L, row-uniform
+  O::bc_lower(F.Lr, L10, L20, L21, L30, L31, L32);
   real b0 = col[0] * F.mkk[0], b1 = col[1] * F.mkk[1], b2 = col[2] * F.mkk[2], b3 = col[3] * F.mkk[3];
   // chol_solve_r, unrolled
   b0 = b0 * F.rinv[0];

@@ -46,6 +46,23 @@ struct Ops {
   template <bool NEG> static void matvec_acc(V &acc, const V &v, const V (&h)[4]) {
     fmac_bc<0, NEG>(acc, v, h[0]); fmac_bc<1, NEG>(acc, v, h[1]); fmac_bc<2, NEG>(acc, v, h[2]); fmac_bc<3, NEG>(acc, v, h[3]);
   }
+  // the multi-instruction blocks of the device version (one wait state in front of several DPP instructions)
+  static void bc4(const V &v, V (&o)[4]) { o[0] = bc<0>(v); o[1] = bc<1>(v); o[2] = bc<2>(v); o[3] = bc<3>(v); }
+  static V sum4(const V &t, const V &one) {
+    V s = bc<0>(t);
+    fmac_bc<1, false>(s, t, one); fmac_bc<2, false>(s, t, one); fmac_bc<3, false>(s, t, one);
+    return s;
+  }
+  // Lc[k] = L[k][r] for k > r: sum_c oh[c] * (L[k][c] from lane k), exact
+  static void transpose_lower(const V (&Lr)[4], const V (&oh)[4], V (&Lc)[4]) {
+    for (int k = 0; k < 4; ++k) Lc[k] = cst(0.0);
+    fmac_bc<1, false>(Lc[1], Lr[0], oh[0]);
+    fmac_bc<2, false>(Lc[2], Lr[0], oh[0]); fmac_bc<2, false>(Lc[2], Lr[1], oh[1]);
+    fmac_bc<3, false>(Lc[3], Lr[0], oh[0]); fmac_bc<3, false>(Lc[3], Lr[1], oh[1]); fmac_bc<3, false>(Lc[3], Lr[2], oh[2]);
+  }
+  static void bc_lower(const V (&Lr)[4], V &L10, V &L20, V &L21, V &L30, V &L31, V &L32) {
+    L10 = bc<1>(Lr[0]); L20 = bc<2>(Lr[0]); L21 = bc<2>(Lr[1]); L30 = bc<3>(Lr[0]); L31 = bc<3>(Lr[1]); L32 = bc<3>(Lr[2]);
+  }
   // the device version looks at lanes 0..3 of the row only (the other quads hold copies)
   static M team_any(const M &p) {
     M r;

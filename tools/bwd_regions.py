@@ -29,7 +29,7 @@ v = np.array(list(out), dtype=np.float64)
 knots = v[15]
 # (nu = 4 runs the team-distributed gains of aslr_team_gains.hpp: regions 6-9 of the per-lane QP stay empty there)
 names = ["top: wait for the record", "step 1", "step 2", "DMA issue", "gains inputs (Quu row, bounds) / first active set", "team gains: factor, Newton point, QP / plain gains",
-         "box decision + QP prologue", "QP head (mask, factor, solve)", "QP line search + gradient", "QP final gains",
+         "  of which: first factor", "  first Newton point, decisions", "  QP line search + gradient", "  QP next active set / factor / Newton point, final factor",
          "tail (Quu k, Vx, Vxx, stores)", "step 4 + loop"]
 names.append("gain column K / after the box branch")
 v = np.concatenate([v[:12], v[16:17], v[12:16]])
@@ -37,5 +37,5 @@ tot = v[:13].sum()
 v = np.concatenate([v[:13], np.zeros(3), v[13:]])
 print("wave-knots %d, cycles per wave-knot %.0f" % (knots, tot / knots))
 for n, c in zip(names, v[:13]): print("  %-32s %8.0f cycles  %5.1f %%" % (n, c / knots, 100 * c / tot))
-print("  QP calls per wave-knot %.3f, QP iterations per call %.3f, plain executions per wave-knot %.3f"
+print("  (old per-lane QP: QP calls per wave-knot, iterations per call, plain executions per wave-knot;\n   team gains: wave-knots that enter the QP loop, line searches per entry, final re-factorisations per wave-knot)\n  %.3f, %.3f, %.3f"
       % (v[17] / knots, v[16] / max(v[17], 1), v[18] / knots))
