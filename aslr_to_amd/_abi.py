@@ -22,8 +22,8 @@ SOLVER_DDP, SOLVER_FDDP, SOLVER_BOXDDP = 0, 1, 2
 ST_CONVERGED, ST_REG_MAX, ST_BACKWARD_ERR, ST_FORWARD_ERR = 1, 2, 4, 8
 
 (R_XS, R_US, R_XNEXT, R_COST, R_DERIV, R_GAPS, R_KGAIN, R_KFF, R_QU, R_VX, R_VXX, R_XS_TRY,
- R_US_TRY, R_TRAJ_F, R_TRAJ_I, R_X0, R_FRAME_REF, R_VXXF, R_DESC, R_NODE_MODEL, R_COST_TRY, R_DYN,
- R_COUNT) = range(23)
+ R_US_TRY, R_TRAJ_F, R_TRAJ_I, R_X0, R_FRAME_REF, R_VXXF, R_DESC, R_NODE_MODEL, R_COST_TRY, R_DYN, R_POOL_SAVE,
+ R_COUNT) = range(24)
 
 (TF_COST, TF_STOP, TF_XREG, TF_D1, TF_D2, TF_STEP, TF_DV, TF_DVEXP, TF_DG, TF_DQ,
  TF_COST_TRY0) = range(11)

@@ -47,11 +47,15 @@ __global__ void __launch_bounds__(64) pool_refill_kernel(KArgs a, PoolDev pl, do
   const int b = blockIdx.x, tid = threadIdx.x, B = a.B, T = a.T, nx = pl.nx, nu = pl.nu;
   int32_t *TI = a.traj_i;
   double *TF = a.traj_f;
+  __shared__ int next_j, skip;
   const int j = pl.slot_problem[b];
-  const int done = TI[ASLR_TI_DONE * B + b];
-  if (j >= 0 && !done) return; // still iterating
-  if (j < 0 && pl.counters[0] >= pl.P) return; // idle and nothing left to hand out (the counter only grows)
-  __shared__ int next_j;
+  if (tid == 0) { // one thread decides for the block (other blocks bump the counter during this launch)
+    const int done = TI[ASLR_TI_DONE * B + b];
+    skip = (j >= 0 && !done)                                                      // still iterating
+           || (j < 0 && __atomic_load_n(&pl.counters[0], __ATOMIC_RELAXED) >= pl.P); // idle, nothing left to hand out (the counter only grows)
+  }
+  __syncthreads();
+  if (skip) return;
   if (j >= 0) { // ---- flush: the last accepted candidate is the solution (solver.xs / solver.us) ----
     const int acc = TI[ASLR_TI_ACCEPTED * B + b];
     double *xo = pl.xs_out + (size_t)j * (T + 1) * nx, *uo = pl.us_out + (size_t)j * T * nu;
@@ -200,6 +204,7 @@ void carve(const aslr_problem_desc_t *d, int nx, int nu, aslr_region_t *r, int64
   sizes[ASLR_R_NODE_MODEL] = T1 * sizeof(int32_t);
   sizes[ASLR_R_COST_TRY] = (int64_t)ASLR_NALPHA * T1 * B * D;
   sizes[ASLR_R_DYN] = T1 * B * dyn_len_c(nx / 4) * D;
+  sizes[ASLR_R_POOL_SAVE] = B * (nx + 12) * D;
   int64_t off = 0;
   for (int i = 0; i < ASLR_R_COUNT; ++i) {
     r[i].offset = off;
@@ -752,6 +757,7 @@ int aslr_solve_pool(aslr_problem_t *p, const aslr_solver_params_t *sp, const asl
   const int B = p->desc.B;
   if (refill_every <= 0) refill_every = 4;
   if (poll_every <= 0) poll_every = 4 * refill_every;
+  if (poll_every > sp->maxiter + refill_every) poll_every = sp->maxiter + refill_every; // (a short maxiter must still be polled)
   PoolDev pl;
   pl.P = pool->P; pl.nx = p->nx; pl.nu = p->nu;
   pl.x0 = pool->x0; pl.frame_ref = pool->frame_ref; pl.xs_out = pool->xs_out; pl.us_out = pool->us_out;
@@ -762,9 +768,17 @@ int aslr_solve_pool(aslr_problem_t *p, const aslr_solver_params_t *sp, const asl
   HIP_TRY(hipMemsetAsync(pool->slot_problem, 0xFF, sizeof(int32_t) * B, st));
   HIP_TRY(hipMemsetAsync(pool->counters, 0, sizeof(int32_t) * 2, st));
   HIP_TRY(hipMemsetAsync(p->k.traj_i + (size_t)ASLR_TI_DONE * B, 0, sizeof(int32_t) * B, st));
+  // the refill overwrites the slots' x0 / frame_ref columns with the pool's: keep the handle's own and put them back
+  // on exit, so that a later solve / rollout on this handle sees the problems it was created with
+  double *save = reinterpret_cast<double *>(p->ws + p->regions[ASLR_R_POOL_SAVE].offset);
+  HIP_TRY(hipMemcpyAsync(save, p->k.x0, sizeof(double) * B * p->nx, hipMemcpyDeviceToDevice, st));
+  if (p->k.frame_ref) HIP_TRY(hipMemcpyAsync(save + (size_t)B * p->nx, p->k.frame_ref, sizeof(double) * B * 12, hipMemcpyDeviceToDevice, st));
   aslr_solver_params_t spi = *sp;
   const KArgs saved = p->k;
   p->k.iter_log = nullptr; p->k.log_cap = 0; // (a slot's iteration index restarts with every problem)
+  // the closed-form reach residual was validated for the references given at create time only (fill_planar_reach):
+  // pool targets take the general log map
+  if (pool->frame_ref) p->k.planar_reach = 0;
   p->pool_maxiter = sp->maxiter;
   int it = 0, rc = ASLR_OK;
   // the slowest possible schedule: every problem takes maxiter iterations, one wave of B problems after the other
@@ -790,10 +804,27 @@ int aslr_solve_pool(aslr_problem_t *p, const aslr_solver_params_t *sp, const asl
       if (fin >= pool->P) break;
     }
   }
+  int32_t fin_total = -1;
+  if (!rc) { // one more flush, then every problem must have been written out
+    hipLaunchKernelGGL(pool_refill_kernel, dim3(B), dim3(64), 0, st, p->k, pl, reg0, sp->is_feasible);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(p->h_done, pool->counters + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) rc = ASLR_E_HIP;
+    else fin_total = p->h_done[0];
+  }
   p->pool_maxiter = 0;
   p->k = saved;
+  {
+    hipError_t e = hipMemcpyAsync(const_cast<double *>(p->k.x0), save, sizeof(double) * B * p->nx, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && p->k.frame_ref) e = hipMemcpyAsync(const_cast<double *>(p->k.frame_ref), save + (size_t)B * p->nx, sizeof(double) * B * 12, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess && !rc) rc = ASLR_E_HIP;
+  }
   if (iters_done) *iters_done = it;
   if (rc) return rc;
+  if (fin_total < pool->P) {
+    snprintf(g_err, sizeof g_err, "aslr_solve_pool: %d of %d problems finished within the iteration bound", fin_total, pool->P);
+    return ASLR_E_INVALID;
+  }
   hipLaunchKernelGGL(reset_accepted_kernel, dim3((B + 255) / 256), dim3(256), 0, st, p->k);
   HIP_TRY(hipGetLastError());
   return ASLR_OK;

@@ -216,11 +216,14 @@ ASLR_DEV void dma_record(const char *g, unsigned recD_addr, int lt, std::integer
 
 // BOX: SolverBoxDDP gains may be needed (solver is BoxDDP); GAPS: infeasible candidates may be present
 // (gap terms, FDDP expected-improvement terms).  A wave whose trajectories need neither runs the lean variant.
+#ifndef ASLR_BWD_WAVES_TEAMQP
+#define ASLR_BWD_WAVES_TEAMQP 1 // register budget of the 16-lane-team nu = 4 kernels as waves per SIMD (2: <= 256, so that calc / cost waves of other sub-shards fit next to a sweep wave)
+#endif
 #ifndef ASLR_BWD_WAVES
 #define ASLR_BWD_WAVES 2 // waves per SIMD the HS = 4 variant (two 32-lane teams per wave) must fit
 #endif
 template <int NX, int NU, int HS, int TPWA, bool BOX, bool GAPS>
-__global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : 1)) backward_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
+__global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : (BwdCfg<NX, NU, HS, TPWA>::TEAMQP ? ASLR_BWD_WAVES_TEAMQP : 1))) backward_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
   using C = BwdCfg<NX, NU, HS, TPWA>;
   constexpr int NXP = C::NXP, TEAM = C::TEAM, TPW = C::TPW, RPL = C::RPL, REC = C::REC;
   // The work arrays are a static allocation in the DMA configuration: the compiler then knows they cannot overlap

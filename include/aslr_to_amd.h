@@ -71,6 +71,13 @@ extern "C" {
 #define ASLR_ST_REG_MAX     2  /* regularisation hit reg_max      -> solve() returned false */
 #define ASLR_ST_BACKWARD_ERR 4 /* at least one Cholesky failure / NaN in a backward pass (recovered by regularisation) */
 #define ASLR_ST_FORWARD_ERR 8  /* at least one line-search trial produced NaN/Inf (that alpha was skipped)             */
+/* CONVERGED and REG_MAX are OUTCOMES (what solve() returns, where it stopped) and BACKWARD_ERR records a decision the
+ * solver took (regularise and redo); these are reproducible and comparable between implementations.  FORWARD_ERR is an
+ * ADVISORY NOTE: it says that some rejected trial rollout overflowed.  A rollout that is rejected anyway can be
+ * unstable (|x| doubling per knot); whether it crosses 1e30 inside the horizon or stays just below depends on the last
+ * bits of the gains, so two correct implementations (or two builds of this one) may disagree on this bit for the same
+ * problem while agreeing on every iterate.  Do not branch on it; the parity tests mask it (tests/_parity.py). */
+#define ASLR_ST_ADVISORY_MASK ASLR_ST_FORWARD_ERR
 
 /* Fixed-base serial chain of revolute joints (stands in for pinocchio.Model; the URDFs of
  * example_robot_data are unobtainable offline, see robots.py).  Joint j's parent is joint j-1
@@ -186,12 +193,15 @@ typedef struct aslr_solver_params {
  *                               the team kernel to the record assembly; only for chains with nj > 2 (else empty)
  *   TRAJ_F  [ASLR_TF_COUNT][B]  per-trajectory doubles (ASLR_TF_*)
  *   TRAJ_I  [ASLR_TI_COUNT][B]  per-trajectory int32   (ASLR_TI_*)
+ *   POOL_SAVE [B][nx + 12]      scratch of aslr_solve_pool (the handle's x0 / frame_ref while pool problems occupy the slots)
  */
 enum aslr_region_id {
   ASLR_R_XS = 0, ASLR_R_US, ASLR_R_XNEXT, ASLR_R_COST, ASLR_R_DERIV, ASLR_R_GAPS,
   ASLR_R_KGAIN, ASLR_R_KFF, ASLR_R_QU, ASLR_R_VX, ASLR_R_VXX, ASLR_R_XS_TRY, ASLR_R_US_TRY,
   ASLR_R_TRAJ_F, ASLR_R_TRAJ_I, ASLR_R_X0, ASLR_R_FRAME_REF, ASLR_R_VXXF, ASLR_R_DESC,
-  ASLR_R_NODE_MODEL, ASLR_R_COST_TRY, ASLR_R_DYN, ASLR_R_COUNT
+  ASLR_R_NODE_MODEL, ASLR_R_COST_TRY, ASLR_R_DYN,
+  ASLR_R_POOL_SAVE /* [B][nx + 12]: the handle's own x0 / frame_ref columns while aslr_solve_pool streams problems through the slots */,
+  ASLR_R_COUNT
 };
 
 /* rows of TRAJ_F */
@@ -296,7 +306,13 @@ int aslr_solve(aslr_problem_t *p, const aslr_solver_params_t *sp, int32_t poll_e
  * of examples/two_dof_sea.py:77-81, or a cold start (xs = 0, us = 0: `solve([], [], maxiter)`) when they are NULL -- and
  * goes through exactly the iterations aslr_solve would give it: results do not depend on B, on the slot or on
  * refill_every, bit for bit.
- * All pointers are DEVICE pointers owned by the caller. */
+ * All pointers are DEVICE pointers owned by the caller.
+ * Side effects on the handle: while the pool runs, the slots' X0 / FRAME_REF columns hold the pool's problems; the
+ * handle's own are kept in POOL_SAVE and put back before the call returns, so a later aslr_solve / rollout sees the
+ * problems the handle was created with.  XS / US / the per-trajectory state are left with the last slot contents
+ * (every solver entry point re-initialises them from its own arguments).  Pool targets always take the general SE(3)
+ * log map (the opt-in closed-form reach residual is validated for the create-time references only).  The call fails
+ * (ASLR_E_INVALID, aslr_last_error) if fewer than P problems were flushed within its iteration bound. */
 typedef struct aslr_pool {
   int32_t P;                  /* problems in the pool                                                          */
   int32_t _pad0;

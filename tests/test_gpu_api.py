@@ -599,6 +599,22 @@ def test_pool_solve_gives_every_problem_the_solve_it_would_get_in_a_batch():
     # a pool smaller than the slots, and a solver without bounds on the same engine afterwards
     r = e.solve_pool(sc["x0"][:10], sc["frame_refs"][:10], sp)
     assert torch.equal(r["xs"], X[:10]) and torch.equal(r["iters"], iters[:10])
+    # a short maxiter (fewer iterations than the polling period) still terminates with every problem flushed
+    sp3 = scenarios.solver_params(sc, maxiter=3)
+    r3 = e.solve_pool(sc["x0"][:100], sc["frame_refs"][:100], sp3, refill_every=4, poll_every=16)
+    assert int(r3["iters"].max()) == 3 and r3["batch_iters"] <= 3 * (3 + 4)
+    # the handle's OWN problems (x0 / targets it was created with) are back after a pool: a plain solve on it equals the
+    # same solve on a fresh engine, bit for bit (aslr_solve_pool used to leave the last pool problems in the slots)
+    e.set_subshards(1)
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=8)
+    fresh = Engine(scenarios.lower(slots))
+    fresh.set_candidate(None, None)
+    fresh.solve(sp, poll_every=8)
+    torch.cuda.synchronize()
+    assert torch.equal(e.region(_abi.R_X0), fresh.region(_abi.R_X0))
+    assert torch.equal(e.region(_abi.R_XS), fresh.region(_abi.R_XS)) and torch.equal(e.region(_abi.R_US), fresh.region(_abi.R_US))
+    assert torch.equal(e.traj_i(_abi.TI_ITER), fresh.traj_i(_abi.TI_ITER))
 
 
 @pytest.mark.parametrize("name,solver,P,slots,T,maxiter", [("two_dof_sea", "SolverFDDP", 150, 40, 25, 60),

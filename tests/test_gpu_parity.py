@@ -473,3 +473,40 @@ def test_c5_horizon_full_solves_match_oracle(oracle):
     print("C5 horizon: converged %d / 16, max rel |dx| %.2e |du| %.2e, |dcost| %.2e" % (conv.sum(), dx[conv].max(), du[conv].max(), dc[conv].max()))
     assert dx[conv].max() < 1e-6 and du[conv].max() < 1e-6
     assert (dc[conv] < 1e-4 * np.maximum(1.0, np.abs(ref["traj_f"][_abi.TF_COST][conv]))).all()
+
+
+@pytest.mark.gpu
+def test_opt_in_closed_form_reach_residual_matches_the_general_log_map_on_the_gpu(oracle, monkeypatch):
+    """ASLR_PLANAR_REACH=1 (closed-form frame-placement residual of planar chains in cost-only evaluations, off by
+    default): the trial costs of every step length agree with the general SE(3) log path to 5e-9 relative (1e-12 typically;
+    Pinocchio's t sin t / (2 (1 - cos t)) in the general path loses digits at small rotation angles) -- on the GPU,
+    not only in the numpy derivation of tests/test_planar_reach_closed_form.py -- and a pool with its own targets falls back
+    to the general path (aslr_solve_pool) instead of mixing the two formulas."""
+    import torch
+    sc = scenarios.two_dof_vsa_boxddp(B=70, T=5)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc)
+    xs, us, deriv, gaps = _backward_inputs(oracle, low, 5)
+    ref_b = oracle.backward_pass(low, sp, deriv, gaps, us, 1e-3, 1)
+    K, k = 0.05 * ref_b["K"], 0.05 * ref_b["k"]
+    costs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("ASLR_PLANAR_REACH", flag)   # (read when the problem handle is created)
+        e = _engine(low)
+        e.region(_abi.R_XS).copy_(torch.as_tensor(xs))
+        e.region(_abi.R_US).copy_(torch.as_tensor(us))
+        e.region(_abi.R_KGAIN).copy_(torch.as_tensor(K))
+        e.region(_abi.R_KFF).copy_(torch.as_tensor(k))
+        e.region(_abi.R_TRAJ_I)[_abi.TI_FEASIBLE].fill_(1)
+        e.forward_pass(sp)
+        _sync()
+        costs[flag] = np.stack([_np(e.traj_f(_abi.TF_COST_TRY0 + a)) for a in range(_abi.NALPHA)])
+        if flag == "1":
+            r1 = e.solve_pool(sc["x0"][:20], sc["frame_refs"][:20], scenarios.solver_params(sc, maxiter=6))
+    ok = np.isfinite(costs["0"])
+    assert ok.mean() > 0.9 and (np.isfinite(costs["1"]) == ok).all()
+    assert _relerr(costs["1"][ok], costs["0"][ok]) < 5e-9
+    assert (costs["1"][ok] != costs["0"][ok]).any()      # the closed form really ran (it rounds differently)
+    monkeypatch.setenv("ASLR_PLANAR_REACH", "0")
+    r0 = _engine(low).solve_pool(sc["x0"][:20], sc["frame_refs"][:20], scenarios.solver_params(sc, maxiter=6))
+    assert torch.equal(r1["xs"], r0["xs"]) and torch.equal(r1["cost"], r0["cost"])
