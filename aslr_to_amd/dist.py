@@ -14,8 +14,9 @@ from .lowering import shard_rows  # noqa: F401  (re-exported)
 STAT_FIELDS = ("cost_sum", "stop_sum", "n", "converged", "failed", "iters_sum", "trials_sum", "active")
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1.
+def init_from_env(backend=None, timeout_s=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1 (`timeout_s`: bound on the
+    rendezvous and on every collective, so that a missing rank raises instead of hanging the others).
     Returns (rank, world_size, local_rank)."""
     import torch
     import torch.distributed as dist
@@ -29,7 +30,11 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
@@ -73,6 +78,20 @@ def max_over_ranks(value, device=None, group=None):
             t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def gather_floats(value, device=None, group=None):
+    """Every rank's float, in rank order, on every rank (all_gather of one double)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "gloo":
+            t = t.cpu()
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(out, t, group=group)
+        return [float(o.item()) for o in out]
+    return [float(value)]
 
 
 def barrier(group=None):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the batched DDP hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5]
 
 With N > 1 and no RANK / WORLD_SIZE in the environment (i.e. not under torch.distributed.run) the script starts its
 own N ranks, one process per GPU (launch_ranks); under torch.distributed.run it is one of the ranks.
@@ -33,9 +33,34 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-T = 100
-B_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# --workload: BASELINE.json configs as one-GPU shards (weak scaling: the same shard on every GPU).  c3 is the headline
+# (configs[2]; configs[3] = 8 x c3); c2 = configs[1]; c5 = configs[4] (4096 trajectories over 8 GPUs = 512 per GPU).
+# `kernels`: the instantiations one iteration launches in steady state, per phase (calc, backward, forward), by their
+# demangled names -- what the committed PMC summary is searched for (exact match, see pmc_traffic).
+WORKLOADS = {
+    "c3": dict(scenario="two_dof_vsa_boxddp", solver="SolverBoxDDP", T=100, batch=4096,
+               metric="knot-steps/s (batched BoxDDP, 2-DoF VSA, T=100, 4096 trajectories per GPU)",
+               what="two_dof_vsa_boxddp (examples/two_dof_vsa_boxddp.py, T=100): SolverBoxDDP, cold start, "
+                    "fixed-iteration mode, full 10-alpha line search every iteration",
+               kernels=["calc_kernel<2, 1, true, true, false, true>", "backward_kernel<8, 4, 2, 0, true, true>",
+                        "rollout_kernel<2, 1, true, false>"],
+               cpu=dict(per_thread=64, single=32, maxiter=None)),
+    "c2": dict(scenario="two_dof_sea", solver="SolverDDP", T=100, batch=1024,
+               metric="knot-steps/s (batched DDP, 2-DoF SEA, T=100, 1024 trajectories per GPU)",
+               what="two_dof_sea (examples/two_dof_sea.py, T=100): SolverDDP (north_star; the script itself uses FDDP), "
+                    "cold start, fixed-iteration mode, full 10-alpha line search every iteration",
+               kernels=["calc_kernel<2, 0, true, true, false, true>", "backward_kernel<8, 2, 2, 0, false, true>",
+                        "rollout_kernel<2, 0, true, false>"],
+               cpu=dict(per_thread=256, single=128, maxiter=None)),
+    "c5": dict(scenario="talos_arm_sea", solver="SolverDDP", T=150, batch=512,
+               metric="knot-steps/s (batched DDP, 7-DoF arm + SEA, T=150, 512 trajectories per GPU = 4096 over 8 GPUs)",
+               what="talos_arm_sea (7-joint chain with SEA actuation, cost stack of examples/two_dof_sea.py, T=150): SolverDDP, "
+                    "cold start, fixed-iteration mode, full 10-alpha line search every iteration",
+               kernels=["dyn_team_kernel<7, 1>", "backward_blk_kernel<28, 7, true>", "rollout_team_kernel<7, 0, false>"],
+               cpu=dict(per_thread=8, single=8, maxiter=30)),
+}
 
 
 def algorithmic_bytes(nx, nu):
@@ -48,51 +73,64 @@ def algorithmic_bytes(nx, nu):
     return p1, p2, p3
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (separate --pmc passes of this
-    same command with --subshards 1, profiles/rNN/bench_pmc.csv): WRITE_SIZE + 2 x FETCH_SIZE, both in KiB -- the gfx950
-    correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE counts wide coalesced reads at half).
-    None when the summary is absent."""
-    path = next((p for p in (os.path.join(ROOT, "profiles", r, "bench_pmc.csv") for r in ("r02", "r01"))
-                 if os.path.exists(p)), None)
-    if path is None:
-        return None
+def pmc_traffic(kernel_name, workload):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (separate --pmc passes of this same
+    command with --subshards 1: profiles/rNN/bench_pmc[_WORKLOAD].csv, newest round first): WRITE_SIZE + 2 x FETCH_SIZE,
+    both in KiB -- the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE counts wide coalesced
+    reads at half).  The kernel must be in the summary under exactly this (demangled) instantiation name: a summary
+    taken before the kernel changed its template signature does not describe it.
+    -> (bytes or None, note): the note names the file and the commit the summary was taken at (its .meta.json)."""
     import csv
-    fetch = write = None
-    for r in csv.DictReader(open(path)):
-        if kernel_prefix in r["kernel"]:
-            if r["counter"] == "FETCH_SIZE":
-                fetch = float(r["median_per_dispatch"])
-            if r["counter"] == "WRITE_SIZE":
-                write = float(r["median_per_dispatch"])
-    if fetch is None or write is None:
-        return None
-    return (2.0 * fetch + write) * 1024.0
+    suffix = "" if workload == "c3" else "_" + workload
+    for rnd in ("r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "bench_pmc%s.csv" % suffix)
+        if not os.path.exists(path):
+            continue
+        meta = {}
+        try:
+            meta = json.load(open(path[:-4] + ".meta.json"))
+        except Exception:
+            pass
+        stamp = "profiles/%s/bench_pmc%s.csv taken at commit %s" % (rnd, suffix, meta.get("commit", "(unrecorded)"))
+        fetch = write = None
+        for r in csv.DictReader(open(path)):
+            if r["kernel"] == "void aslr::" + kernel_name:
+                if r["counter"] == "FETCH_SIZE":
+                    fetch = float(r["median_per_dispatch"])
+                if r["counter"] == "WRITE_SIZE":
+                    write = float(r["median_per_dispatch"])
+        if fetch is None or write is None:
+            return None, "no FETCH_SIZE / WRITE_SIZE rows for `%s` in %s: the summary does not describe this kernel" % (kernel_name, stamp)
+        return (2.0 * fetch + write) * 1024.0, "bytes per launch (not live): " + stamp
+    return None, "no PMC summary committed for workload %s" % workload
 
 
-def cpu_baseline(sc_fn, nthreads):
-    """Oracle (CPU port) solving the first trajectories of the same batch in converge mode."""
+def cpu_baseline(w, nthreads):
+    """Oracle (CPU port) solving the first trajectories of the same batch in converge mode (a bounded sample)."""
     from aslr_to_amd import _abi, scenarios
     from oracle import pyoracle
-    nsample = 64 * nthreads   # ~8 s of wall time on 16 host cores (~2 minutes of CPU work)
+    sc_fn, T, cfg = scenarios.SCENARIOS[w["scenario"]], w["T"], w["cpu"]
+    kw = {} if cfg["maxiter"] is None else {"maxiter": cfg["maxiter"]}
+    nsample = cfg["per_thread"] * nthreads   # c3: ~8 s of wall time on 16 host cores (~2 minutes of CPU work)
     sc = sc_fn(B=nsample, T=T, seed=0)
     low = scenarios.lower(sc)
-    sp = scenarios.solver_params(sc)
+    sp = scenarios.solver_params(sc, solver=w["solver"], **kw)
     t0 = time.perf_counter()
     r = pyoracle.solve(low, sp, nthreads=nthreads)
     dt = time.perf_counter() - t0
     iters = int(r["traj_i"][_abi.TI_ITER].sum())
-    # mode (i) of SURVEY.md 8(d): one thread, the reference's forced nthreads = 1 (first 32 trajectories)
-    sc1 = sc_fn(B=32, T=T, seed=0)   # ~4 s
+    # mode (i) of SURVEY.md 8(d): one thread, the reference's forced nthreads = 1
+    sc1 = sc_fn(B=cfg["single"], T=T, seed=0)
     low1 = scenarios.lower(sc1)
     t0 = time.perf_counter()
-    r1 = pyoracle.solve(low1, scenarios.solver_params(sc1), nthreads=1)
+    r1 = pyoracle.solve(low1, scenarios.solver_params(sc1, solver=w["solver"], **kw), nthreads=1)
     dt1 = time.perf_counter() - t0
     single = int(r1["traj_i"][_abi.TI_ITER].sum()) * T / dt1
     return {"value": iters * T / dt, "unit": "knot-steps/s", "cores": nthreads, "kind": "port",
             "single_thread_value": single,
-            "sample": "first %d trajectories of the seed-0 batch, full BoxDDP solves (th_stop 1e-7, maxiter 400), "
-                      "%d DDP iterations in %.2f s, OpenMP over trajectories" % (nsample, iters, dt),
+            "sample": "first %d trajectories of the seed-0 batch, full %s solves (th_stop 1e-7, maxiter %s), "
+                      "%d DDP iterations in %.2f s, OpenMP over trajectories"
+                      % (nsample, w["solver"], sp.maxiter, iters, dt),
             "single_thread_note": "the reference forces nthreads = 1 (examples/double_pendulum.py:54)"}
 
 
@@ -141,7 +179,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=B_PER_GPU)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3",
+                    help="c3: 2-DoF VSA BoxDDP, 4096 per GPU (headline); c2: 2-DoF SEA DDP, 1024; c5: 7-DoF SEA DDP, T=150, 512 per GPU")
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="trajectories per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--subshards", type=int, default=4,
                     help="iterate each GPU's shard as this many sub-shards on internal streams (1 = off)")
@@ -172,7 +212,10 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_env))
     if not rehearsal and torch.cuda.device_count() < args.gpus:
         raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
-    rank, world, local = dist.init_from_env("gloo" if rehearsal else None)
+    try:
+        rank, world, local = dist.init_from_env("gloo" if rehearsal else None, timeout_s=float(os.environ.get("ASLR_BENCH_INIT_TIMEOUT", "180")))
+    except Exception as exc:  # a rank that cannot join must not leave the others waiting for ever
+        raise SystemExit("bench.py: torch.distributed rendezvous failed (rank %s of %s): %s" % (os.environ.get("RANK"), world_env, exc))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local if world > 1 and not rehearsal else 0)
@@ -180,12 +223,14 @@ def main():
     backend = torch.distributed.get_backend() if world > 1 else None
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    Bg = args.batch_per_gpu
-    sc = scenarios.two_dof_vsa_boxddp(B=Bg * world, T=T, seed=0)
+    w = WORKLOADS[args.workload]
+    T = w["T"]
+    Bg = args.batch_per_gpu or w["batch"]
+    sc = scenarios.SCENARIOS[w["scenario"]](B=Bg * world, T=T, seed=0)
     problem = ShootingProblem(sc["x0"], sc["running"], sc["terminal"], frame_refs=sc["frame_refs"],
                               rank=rank, world_size=world, device=dev)
     e = problem.engine
-    sp = scenarios.solver_params(sc, fixed_iterations=1, maxiter=args.warmup + args.steps)
+    sp = scenarios.solver_params(sc, solver=w["solver"], fixed_iterations=1, maxiter=args.warmup + args.steps)
     e.set_candidate(None, None)  # cold start, as examples/two_dof_vsa_boxddp.py:81
     # The shard is iterated as sub-shards on internal streams (same results bit for bit: trajectories are independent;
     # the one-wave-per-SIMD sweeps of a sub-shard run under the streaming kernels of the others).  The K steps are
@@ -200,7 +245,9 @@ def main():
     e.iterate_n(sp, args.warmup == 0, args.steps)
     torch.cuda.synchronize(dev)
     dist.barrier()
-    elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
+    mine = time.perf_counter() - t0
+    elapsed = dist.max_over_ranks(mine, dev)
+    per_rank_ms = [v / args.steps * 1e3 for v in dist.gather_floats(mine, dev)]  # (a slow GPU shows in the line)
 
     # per-kernel durations: HIP events on the launch stream around each phase, with the whole shard as ONE launch per
     # kernel (aslr_iterate_timed does not use the sub-shard streams), a few more iterations of the same solve
@@ -218,6 +265,8 @@ def main():
     # every trajectory of the shard has stopped -- timed once, outside the figure of merit above (off by default so
     # that a rocprofv3 run of the default command averages the fixed-iteration launches only)
     converge = None
+    if args.converge_mode and args.workload != "c3":
+        raise SystemExit("bench.py: --converge-mode is defined for the headline workload (c3) only")
     if args.converge_mode:
         spc = scenarios.solver_params(sc)
         e.set_candidate(None, None)
@@ -259,7 +308,9 @@ def main():
     value = knot_steps / elapsed
     p1, p2, p3 = algorithmic_bytes(e.nx, e.nu)
     names = ["calc_kernel", "backward_kernel", "forward (rollout + trial_cost + sum_cost + select kernels)"]
-    pmc_names = ["aslr::calc_kernel<2, 1, true", "aslr::backward_kernel", "aslr::rollout_kernel"]
+    if args.workload == "c5":
+        names = ["calcDiff (dyn_team_kernel x 2 + calc_kernel)", "backward_blk_kernel",
+                 "forward (rollout_team + trial_cost + sum_cost + select kernels)"]
     # the sequential line search of the algorithm needs (accepted index + 1) trials; the kernel evaluates
     # all 10 step lengths at once, but only the required ones count as algorithmic traffic
     trials = stats["trials_sum"] / max(stats["iters_sum"], 1)
@@ -267,17 +318,17 @@ def main():
     dom = max(range(3), key=lambda i: k_ms[i])
     launch_bytes = phase_bytes[dom] * Bg * T
     achieved = launch_bytes / (k_ms[dom] * 1e-3) / 1e9
+    traffic, traffic_note = pmc_traffic(w["kernels"][dom], args.workload)
     out = {
-        "metric": "knot-steps/s (batched BoxDDP, 2-DoF VSA, T=100, 4096 trajectories per GPU)",
+        "metric": w["metric"] if Bg == w["batch"] else w["metric"].replace("%d trajectories per GPU" % w["batch"], "%d trajectories per GPU" % Bg),
         "value": value, "unit": "knot-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearsal else ""),
-        "config": {"workload": "two_dof_vsa_boxddp (examples/two_dof_vsa_boxddp.py, T=100): SolverBoxDDP, "
-                               "cold start, fixed-iteration mode, full 10-alpha line search every iteration",
+        "config": {"workload": w["what"], "workload_id": args.workload,
                    "batch_per_gpu": Bg, "global_batch": Bg * world, "T": T, "nx": e.nx, "nu": e.nu,
                    "subshards_per_gpu": args.subshards,
                    "sharding": "contiguous batch blocks, no data-path collective"},
-        "ranks": {"world_size": ranks_seen, "backend": backend,
+        "ranks": {"world_size": ranks_seen, "backend": backend, "ms_per_step": per_rank_ms,
                   "launcher": "bench.py" if os.environ.get("ASLR_BENCH_SELF_LAUNCHED") == "1" else
                               ("torch.distributed.run" if world > 1 else "single process"),
                   "note": "world size as torch.distributed reports it after init (nccl = RCCL over xGMI)"},
@@ -290,15 +341,15 @@ def main():
         "kernel_ms_note": "whole-shard launches on one stream (sub-shards off), HIP events; their sum is the "
                           "iteration without overlap, ms_per_step the iteration with the sub-shard streams",
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc_names[dom]),
-                     "traffic_note": "bytes per launch, newest rocprofv3 PMC summary committed under profiles/ (not live)",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                     "kernel_instantiation": w["kernels"][dom],
                      "algorithmic_bytes_per_launch": launch_bytes,
                      "algorithmic_bytes_per_knot_step": phase_bytes[dom],
                      "knot_steps_per_launch": Bg * T},
         "roofline_iteration": {"algorithmic_bytes_per_knot_step": p1 + p2 + p3,
                                "achieved": (p1 + p2 + p3) * value / world / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s per GPU", "frac": (p1 + p2 + p3) * value / world / 1e9 / HBM_PEAK_GBS,
-                               "note": "SURVEY.md 8(d) whole-iteration figure (4496 B per knot-step at nx=8, nu=4)"},
+                               "note": "SURVEY.md 8(d) whole-iteration figure (%d B per knot-step at nx=%d, nu=%d)" % (p1 + p2 + p3, e.nx, e.nu)},
         "solver_state": stats,
     }
     if world == 1 and not args.no_cpu_baseline:
@@ -307,7 +358,7 @@ def main():
         except AttributeError:
             nthreads = os.cpu_count() or 1
         nthreads = min(nthreads, 16)  # the CPU share of a one-GPU box
-        out["cpu_baseline"] = cpu_baseline(scenarios.two_dof_vsa_boxddp, nthreads)
+        out["cpu_baseline"] = cpu_baseline(w, nthreads)
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 

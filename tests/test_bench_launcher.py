@@ -48,3 +48,23 @@ def test_world_size_mismatch_is_rejected():
                              capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
         assert out.returncode != 0 and out.stdout.strip() == ""
         assert "--gpus %s but WORLD_SIZE=2" % gpus in out.stderr
+
+
+def test_eight_rank_environments_and_a_missing_rank_times_out_instead_of_hanging():
+    """The day-one 8-GPU launch: eight rank environments with one rendezvous; and a rank whose peers never arrive leaves
+    with a non-zero exit code after the bounded rendezvous timeout (ASLR_BENCH_INIT_TIMEOUT) -- it does not wait for ever."""
+    bench = _bench_module()
+    envs = [bench.rank_env(r, 8, 29555, {"PATH": "/usr/bin"}) for r in range(8)]
+    assert sorted(int(e["RANK"]) for e in envs) == list(range(8)) and {e["WORLD_SIZE"] for e in envs} == {"8"}
+    assert len({e["MASTER_PORT"] for e in envs}) == 1
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, ASLR_BENCH_REHEARSAL="1", ASLR_BENCH_INIT_TIMEOUT="5")
+    env.update(bench.rank_env(0, 2, port, {}))   # rank 0 of 2; rank 1 is never started
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--batch-per-gpu", "8"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "rendezvous failed" in out.stderr or "needs a ROCm GPU" in out.stderr

@@ -510,3 +510,56 @@ def test_opt_in_closed_form_reach_residual_matches_the_general_log_map_on_the_gp
     monkeypatch.setenv("ASLR_PLANAR_REACH", "0")
     r0 = _engine(low).solve_pool(sc["x0"][:20], sc["frame_refs"][:20], scenarios.solver_params(sc, maxiter=6))
     assert torch.equal(r1["xs"], r0["xs"]) and torch.equal(r1["cost"], r0["cost"])
+
+
+@pytest.mark.gpu
+def test_c2_as_baseline_states_it_1024_sea_ddp_full_solves(oracle):
+    """BASELINE.json configs[1] at its full size: 2-DoF SEA, SolverDDP, 1024 trajectories x T = 100, full solves
+    (th_stop 1e-7, maxiter 100; the oracle needs ~1 s on the host cores).  Every trajectory must take the oracle's number
+    of iterations and end with its status word; iterates within 1e-6, costs within 1e-4 (measured: 6e-13)."""
+    import os
+    sc = scenarios.two_dof_sea(B=1024, T=100, seed=0)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc, solver="SolverDDP")
+    ref = oracle.solve(low, sp, nthreads=min(16, len(os.sched_getaffinity(0))))
+    e = _engine(low)
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=4)
+    _sync()
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_ITER)), ref["traj_i"][_abi.TI_ITER])
+    np.testing.assert_array_equal(_np(e.traj_i(_abi.TI_STATUS)), ref["traj_i"][_abi.TI_STATUS])
+    conv = (ref["traj_i"][_abi.TI_STATUS] & _abi.ST_CONVERGED) != 0
+    assert conv.sum() > 1000
+    dx = np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max()
+    du = np.abs(_np(e.region(_abi.R_US)) - ref["us"]).max()
+    dc = np.abs(_np(e.traj_f(_abi.TF_COST)) - ref["traj_f"][_abi.TF_COST]).max()
+    print("C2 1024 x 100: converged %d, iterations %d..%d, dx %.2e du %.2e dcost %.2e"
+          % (conv.sum(), ref["traj_i"][_abi.TI_ITER].min(), ref["traj_i"][_abi.TI_ITER].max(), dx, du, dc))
+    assert dx < 1e-6 and du < 1e-6 and dc < 1e-4
+
+
+@pytest.mark.gpu
+def test_vsa_modified_examples_own_problem_full_solve(oracle):
+    """examples/two_dof_vsa_modified.py:59-81 as the script runs it: ITS problem (trajectory 0 of the scenario: x0 = 0, the
+    script's target), T = 200, solve([], [], 400).  The stiffness block of Quu has no curvature of its own there (linear
+    cost, u_reg 1e-9), which makes RANDOM variations of the problem part ways with any differently rounded solver
+    (profiles/r02/parity_vsa_modified_64.txt) -- the example itself ends within north_star's tolerances of the oracle
+    with the oracle's iteration count, which is what this test pins."""
+    sc = scenarios.two_dof_vsa_modified(B=1, T=200, seed=0)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc)
+    assert sp.maxiter == 400
+    ref = oracle.solve(low, sp)
+    e = _engine(low)
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=8)
+    _sync()
+    it_g, it_r = int(_np(e.traj_i(_abi.TI_ITER))[0]), int(ref["traj_i"][_abi.TI_ITER][0])
+    st_g, st_r = int(_np(e.traj_i(_abi.TI_STATUS))[0]), int(ref["traj_i"][_abi.TI_STATUS][0])
+    dx = np.abs(_np(e.region(_abi.R_XS)) - ref["xs"]).max()
+    du = np.abs(_np(e.region(_abi.R_US)) - ref["us"]).max()
+    dc = abs(float(_np(e.traj_f(_abi.TF_COST))[0]) - float(ref["traj_f"][_abi.TF_COST][0]))
+    print("two_dof_vsa_modified T=200: iterations gpu %d oracle %d, status %d / %d, dx %.2e du %.2e dcost %.2e"
+          % (it_g, it_r, st_g, st_r, dx, du, dc))
+    assert it_g == it_r and (st_g & ~_abi.ST_FORWARD_ERR) == (st_r & ~_abi.ST_FORWARD_ERR)
+    assert dx < 1e-6 and du < 1e-6 and dc < 1e-4
