@@ -73,7 +73,11 @@ class _NodeData(object):
         self.pinocchio = self.multibody.pinocchio
 
     def _blk(self, name):
-        return self._p.engine.deriv_block(name)[self._t, 0].cpu().numpy()
+        e = self._p.engine
+        blk = e.deriv_block(name)[self._t, 0].cpu().numpy()
+        if name in ("Fu", "Lu", "Lxu", "Luu"):
+            blk = e.cut_u(blk)
+        return e.cut_u(blk, axis=-2) if name == "Luu" else blk
 
     @property
     def r(self):
@@ -85,7 +89,7 @@ class _NodeData(object):
         u = e.region(_abi.R_US)[t, 0].cpu().numpy() if t < p.T else model.differential._default_u()
         mi = int(p.lowered.node_model[t])
         dam = model.differential
-        return dam.costs.order_residuals(e.dam_residuals(mi, x, u)[0], dam.state.ndx, dam.nu)
+        return dam.costs.order_residuals(e.dam_residuals(mi, x, u)[0], dam.state.ndx, dam.nu, dam.nu_dev)
 
     xnext = property(lambda s: s._p.engine.region(_abi.R_XNEXT)[s._t, 0].cpu().numpy())
     cost = property(lambda s: float(s._p.engine.region(_abi.R_COST)[s._t, 0].item()))
@@ -126,7 +130,7 @@ class ShootingProblem(object):
         fr = None if frame_refs is None else list(frame_refs)[lo:hi]
         self._lowered = lower_problem(x0[lo:hi], self.runningModels, terminalModel, fr)
         self.batch = hi - lo
-        self.nx, self.nu = self._lowered.nx, self._lowered.nu
+        self.nx, self.nu = self._lowered.nx, self._lowered.nu_user
         self._device = device
         self._engine = None
 
@@ -198,7 +202,7 @@ class ShootingProblem(object):
         e.region(_abi.R_US).zero_()
         e.quasi_static(maxiter, tol)
         torch.cuda.synchronize(e.device)
-        U = e.region(_abi.R_US).permute(1, 0, 2)
+        U = e.cut_u(e.region(_abi.R_US).permute(1, 0, 2))
         return [u for u in U[0].cpu().numpy()] if self.batch == 1 else U.clone()
 
     @property
@@ -407,7 +411,7 @@ class SolverDDP(object):
         nj = e.nx // 4
         dt = float(self.problem.runningModels[0].dt)
         sel = slice(None) if trajectory is None else int(trajectory)
-        vsa = e.nu == 2 * nj
+        vsa = e.nu_user == 2 * nj
         np.savez(path, t=np.arange(self.problem.T) * dt, q=X[sel][..., :nj], u=U[sel][..., :nj],
                  stiffness=U[sel][..., nj:] if vsa else np.zeros(U[sel].shape[:-1] + (0,)), xs=X[sel], us=U[sel])
         return path
@@ -439,6 +443,7 @@ class SolverDDP(object):
     @property
     def us(self):
         _, U = self._current_xu()
+        U = self.problem.engine.cut_u(U)
         return [u for u in U[0].cpu().numpy()] if self._single() else U
 
     def _tf(self, row):
@@ -480,6 +485,8 @@ class SolverDDP(object):
         e = self.problem.engine
         torch.cuda.synchronize(e.device)
         v = e.region(rid)
+        if rid in (_abi.R_KGAIN, _abi.R_KFF, _abi.R_QU):  # [T, B, nu(, nx)]: the models' own controls
+            v = e.cut_u(v, axis=2)
         return [g for g in v[:, 0].cpu().numpy()] if self._single() else v.transpose(0, 1)
 
     def _value(self, rid):

@@ -11,7 +11,7 @@
 // pivot row broadcast the same way.  ~3x fewer instructions and ~1/4 of the registers.
 //
 // The arithmetic per ENTRY is the arithmetic of the per-lane version it replaces (`boxqp<NU>`, `chol_rs`,
-// `chol_solve_r` in aslr_backward.inc.hpp) and of the oracle (oracle/aslr_oracle.c:865-957, 479-505): same
+// `chol_solve_r` in aslr_backward.inc.hpp) and of the CPU restatement the tests check against (its BoxQP, chol, chol_solve): same
 // operations in the same order; the free / clamped split is carried by exact 0/1 masks as before.
 //
 // The code is written against an `Ops` policy so that the SAME source runs (a) on the GPU with real = double and

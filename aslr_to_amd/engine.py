@@ -30,6 +30,7 @@ class Engine(object):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.low = lowered
         self.B, self.T, self.nx, self.nu, self.rec = lowered.B, lowered.T, lowered.nx, lowered.nu, lowered.rec
+        self.nu_user = getattr(lowered, "nu_user", lowered.nu)  # < nu: controls are padded on the device (pad_u / cut_u)
         nbytes = self.lib.aslr_workspace_bytes(C.byref(lowered.desc))
         if nbytes <= 0:
             raise _abi.AslrError("invalid problem description (aslr_workspace_bytes = %d)" % nbytes)
@@ -114,6 +115,23 @@ class Engine(object):
     def us(self):
         return self.region(_abi.R_US).permute(1, 0, 2)
 
+    def pad_u(self, u):
+        """[..., nu_user] -> [..., nu] (zeros in the padded commands); tensors and arrays pass through otherwise."""
+        if self.nu_user == self.nu or u.shape[-1] != self.nu_user:
+            return u
+        torch = _torch()
+        if torch.is_tensor(u):
+            return torch.cat([u, torch.zeros(u.shape[:-1] + (self.nu - self.nu_user,), dtype=u.dtype, device=u.device)], dim=-1)
+        return np.concatenate([u, np.zeros(u.shape[:-1] + (self.nu - self.nu_user,))], axis=-1)
+
+    def cut_u(self, v, axis=-1):
+        """the models' own controls out of a device-sized array (axis = the control axis)"""
+        if self.nu_user == self.nu:
+            return v
+        idx = [slice(None)] * v.ndim
+        idx[axis] = slice(0, self.nu_user)
+        return v[tuple(idx)]
+
     def deriv_block(self, name):
         """[T+1, B, rows, cols] view of one block of the DERIV records."""
         o = _abi.record_offsets(self.nx, self.nu)
@@ -146,6 +164,7 @@ class Engine(object):
                                 dtype=torch.float64, device=self.device)
             if u.dim() == 2:
                 u = u.unsqueeze(0).expand(self.B, -1, -1)
+            u = self.pad_u(u)
             if tuple(u.shape) != (self.B, self.T, self.nu):
                 raise ValueError("us must have shape [B=%d, T=%d, nu=%d]" % (self.B, self.T, self.nu))
             U.copy_(u.permute(1, 0, 2))
@@ -239,7 +258,7 @@ class Engine(object):
         """Stacked cost residuals (data.r) of n points, in the order of the model's cost list: numpy [n, nr]."""
         torch = _torch()
         x = np.atleast_2d(np.asarray(x, dtype=np.float64))
-        u = np.atleast_2d(np.asarray(u, dtype=np.float64))
+        u = self.pad_u(np.atleast_2d(np.asarray(u, dtype=np.float64)))
         nr = self.lib.aslr_residual_len(C.byref(self.low.desc.models[model_index]), self.nx // 4)
         if nr < 0:
             raise _abi.AslrError("aslr_residual_len failed")
@@ -274,7 +293,7 @@ class Engine(object):
                 if tuple(xi.shape) != (P, self.T + 1, self.nx):
                     raise ValueError("xs_init must have shape [P, T+1, nx]")
             if us_init is not None:
-                ui = torch.as_tensor(us_init, dtype=torch.float64, device=self.device).contiguous()
+                ui = self.pad_u(torch.as_tensor(us_init, dtype=torch.float64, device=self.device)).contiguous()
                 if tuple(ui.shape) != (P, self.T, self.nu):
                     raise ValueError("us_init must have shape [P, T, nu]")
             xs = torch.empty((P, self.T + 1, self.nx), dtype=torch.float64, device=self.device)
@@ -294,7 +313,7 @@ class Engine(object):
         self._call("aslr_solve_pool", C.byref(sp), C.byref(pool), int(refill_every), int(poll_every), self._stream(),
                    C.byref(it))
         torch.cuda.synchronize(self.device)
-        return dict(xs=xs, us=us, cost=sf[:, 0], stop=sf[:, 1], x_reg=sf[:, 2], step=sf[:, 3], iters=si[:, 0],
+        return dict(xs=xs, us=self.cut_u(us), cost=sf[:, 0], stop=sf[:, 1], x_reg=sf[:, 2], step=sf[:, 3], iters=si[:, 0],
                     status=si[:, 1], batch_iters=it.value)
 
     def traj_f(self, row):
@@ -307,7 +326,7 @@ class Engine(object):
         """DAM-level calc + calcDiff on n points (numpy in / numpy out)."""
         torch = _torch()
         x = np.atleast_2d(np.asarray(x, dtype=np.float64))
-        u = np.atleast_2d(np.asarray(u, dtype=np.float64))
+        u = self.pad_u(np.atleast_2d(np.asarray(u, dtype=np.float64)))
         n, nx, nu, nv = x.shape[0], self.nx, self.nu, self.nx // 2
         dx = torch.as_tensor(x, device=self.device).contiguous()
         du = torch.as_tensor(u, device=self.device).contiguous()
@@ -317,7 +336,11 @@ class Engine(object):
         p = lambda k: C.c_void_p(t[k].data_ptr())
         self._call("aslr_dam_eval", model_index, n, C.c_void_p(dx.data_ptr()), C.c_void_p(du.data_ptr()), p("xout"),
                    p("cost"), p("Fx"), p("Fu"), p("Lx"), p("Lu"), p("Lxx"), p("Lxu"), p("Luu"), self._stream())
-        return {k: v.cpu().numpy() for k, v in t.items()}
+        out = {k: v.cpu().numpy() for k, v in t.items()}
+        if self.nu_user != self.nu:
+            out["Fu"], out["Lu"], out["Lxu"] = self.cut_u(out["Fu"]), self.cut_u(out["Lu"]), self.cut_u(out["Lxu"])
+            out["Luu"] = self.cut_u(self.cut_u(out["Luu"]), axis=-2)
+        return out
 
 
 class _PointEvaluator(object):
@@ -359,7 +382,7 @@ class _PointEvaluator(object):
         e = self.engine
         dam = self.iam.differential
         r = e.dam_residuals(0, x, u)[0]
-        ddata.r = dam.costs.order_residuals(r, dam.state.ndx, dam.nu)
+        ddata.r = dam.costs.order_residuals(r, dam.state.ndx, dam.nu, dam.nu_dev)
         ddata.multibody.pinocchio.oMf = _FrameMap(e, dam.state.pinocchio, np.asarray(x, dtype=np.float64))
 
     def integrated(self, data, x, u, diff):
@@ -381,7 +404,12 @@ class _PointEvaluator(object):
             data.r = data.differential.r  # integrated_action.py:17-18
         if diff:
             for k in ("Fx", "Fu", "Lx", "Lu", "Lxx", "Lxu", "Luu"):
-                getattr(data, k)[...] = e.deriv_block(k)[0, 0].cpu().numpy()
+                blk = e.deriv_block(k)[0, 0].cpu().numpy()
+                if k in ("Fu", "Lu", "Lxu", "Luu"):
+                    blk = e.cut_u(blk)
+                if k == "Luu":
+                    blk = e.cut_u(blk, axis=-2)
+                getattr(data, k)[...] = blk
 
 
 class _SE3View(object):

@@ -13,9 +13,12 @@ from . import _abi
 class LoweredProblem(object):
     """Owns the ctypes description and the numpy buffers its pointers refer to."""
 
-    def __init__(self, desc, node_model, x0, frame_ref, nj, nx, nu, dam):
+    def __init__(self, desc, node_model, x0, frame_ref, nj, nx, nu, dam, nu_user=None):
         self.desc, self.node_model, self.x0, self.frame_ref = desc, node_model, x0, frame_ref
         self.nj, self.nx, self.nu, self.dam = nj, nx, nu, dam
+        # nu: control size on the device; nu_user: the models' own nu (smaller for a pendulum actuation with one motor
+        # command: the lowered controls are padded, models._DifferentialBase.lower)
+        self.nu_user = nu if nu_user is None else nu_user
         self.B, self.T = desc.B, desc.T
         self.rec = _abi.record_len(nx, nu)
 
@@ -47,13 +50,14 @@ def lower_problem(x0s, running_models, terminal_model, frame_refs=None):
             index[key] = len(table)
             table.append(m)
         node_model[t] = index[key]
-    nu = table[0].nu
+    nu_user = table[0].nu
+    nu = table[0].differential.nu_dev
     dam = table[0].differential.dam
     desc = _abi.ProblemDesc()
     desc.B, desc.T, desc.nmodels = B, T, len(table)
     desc.chain = chain_model.to_struct()
     for i, m in enumerate(table):
-        if m.nu != nu or m.differential.dam != dam:
+        if m.nu != nu_user or m.differential.dam != dam:
             raise ValueError("all action models of a problem must share nu and the actuation kind")
         desc.models[i] = m.lower()
     fr = None
@@ -68,7 +72,7 @@ def lower_problem(x0s, running_models, terminal_model, frame_refs=None):
         desc.frame_ref = fr.ctypes.data_as(C.POINTER(C.c_double))
     desc.node_model = node_model.ctypes.data_as(C.POINTER(C.c_int32))
     desc.x0 = x0.ctypes.data_as(C.POINTER(C.c_double))
-    return LoweredProblem(desc, node_model, x0, fr, nj, nx, nu, dam)
+    return LoweredProblem(desc, node_model, x0, fr, nj, nx, nu, dam, nu_user)
 
 
 def shard_rows(B, rank, world_size):

@@ -203,11 +203,14 @@ class CostModelSum(object):
     def nr(self):
         return sum((self.costs[n].cost.nr or 0) for n in self._order if self.costs[n].active)
 
-    def order_residuals(self, r, nx, nu):
+    def order_residuals(self, r, nx, nu, nu_dev=None):
         """`r` holds the residual vectors of the active costs stacked in insertion order (the order of the lowered
         cost list, aslr_dam_residuals); returns them stacked the way Crocoddyl's CostModelSum does: its cost items
-        live in a std::map keyed by name, so data.r follows the ALPHABETICAL order of the cost names."""
+        live in a std::map keyed by name, so data.r follows the ALPHABETICAL order of the cost names.
+        nu_dev > nu: the device works on controls padded to nu_dev (see _DifferentialBase.lower); the padded entries of
+        a control residual are dropped here."""
         seg, off = {}, 0
+        pad = 0 if nu_dev is None else int(nu_dev) - int(nu)
         for name in self._order:
             item = self.costs[name]
             if not item.active:
@@ -215,24 +218,27 @@ class CostModelSum(object):
             n = int(item.cost.nr or 0)
             seg[name] = r[off:off + n]
             off += n
+            if pad and isinstance(item.cost, CostModelResidual) and isinstance(item.cost.residual, ResidualModelControl):
+                off += pad
         if off != len(r):
             raise ValueError("residual vector has %d entries, the cost stack %d" % (len(r), off))
         return np.concatenate([seg[k] for k in sorted(seg)]) if seg else np.zeros(0)
 
-    def lower(self, nj, nx, nu):
-        """-> list of _abi.Cost in insertion order."""
+    def lower(self, nj, nx, nu, nu_dev=None):
+        """-> list of _abi.Cost in insertion order (nu_dev: the padded control size of the device, default nu)."""
         out = []
         for name in self._order:
             item = self.costs[name]
             if not item.active:
                 continue
-            out.append(_lower_cost(item.cost, item.weight, nj, nx, nu))
+            out.append(_lower_cost(item.cost, item.weight, nj, nx, nu, nu if nu_dev is None else nu_dev))
         if len(out) > _abi.MAX_COSTS:
             raise ValueError("at most %d cost terms per CostModelSum are supported" % _abi.MAX_COSTS)
         return out
 
 
-def _lower_cost(cost, weight, nj, nx, nu):
+def _lower_cost(cost, weight, nj, nx, nu, nu_dev=None):
+    nu_dev = nu if nu_dev is None else nu_dev
     c = _abi.Cost()
     c.weight = weight
     if isinstance(cost, CostModelResidual):
@@ -274,6 +280,9 @@ def _lower_cost(cost, weight, nj, nx, nu):
             for k in range(nu):
                 c.act_w[k] = w[k]
                 c.ref[k] = uref[k]
+            for k in range(nu, nu_dev):  # padded controls stay at zero: unit weight, zero reference (their own pivot in Quu)
+                c.act_w[k] = 1.0
+                c.ref[k] = 0.0
         else:
             raise TypeError("unsupported residual model %r" % type(res).__name__)
     elif isinstance(cost, CostModelDoublePendulum):
@@ -348,9 +357,15 @@ class _DifferentialBase(object):
         """-> _abi.Model for IntegratedActionModelEulerASR(self, dt)."""
         nj = self.state.pinocchio.nv
         nx, nu = self.state.ndx, self.nu
+        # ActuationModelDoublePendulum(state, actLink, nu=1) (python/aslr_to/__init__.py:262-290): fewer motor commands
+        # than joints.  The kernels are built for nu = nj, so the model is lowered with the controls PADDED to nj: zero
+        # columns in S (the padded commands drive nothing: zero Fu columns, zero gradient, zero gains), unit weight in a
+        # control cost so that they keep a pivot of their own in Quu, unit box.  The Python layer pads / slices at its
+        # boundary (Engine.set_candidate, solver.us / K / k / Qu, data.Fu ...).
+        nu_dev = self.nu_dev
         m = _abi.Model()
         m.dam = self.dam
-        m.nu = nu
+        m.nu = nu_dev
         m.dt = float(dt)
         K = np.zeros((nj, nj)) if self.dam == _abi.DAM_VSA else np.asarray(self.K, dtype=float).reshape(nj, nj)
         Bm = np.asarray(self.B, dtype=float).reshape(nj, nj)
@@ -359,12 +374,13 @@ class _DifferentialBase(object):
         for k, v in enumerate(Bm.reshape(-1)):
             m.B[k] = v
         if self.dam == _abi.DAM_SEA:
-            if nu != nj:
-                raise ValueError("SEA models need nu == number of joints (got nu=%d, nj=%d)" % (nu, nj))
-            S = np.asarray(self.actuation.motor_matrix(), dtype=float).reshape(nj, nu)
+            if nu > nj or nu < 1:
+                raise ValueError("SEA models need 1 <= nu <= number of joints (got nu=%d, nj=%d)" % (nu, nj))
+            S = np.zeros((nj, nu_dev))
+            S[:, :nu] = np.asarray(self.actuation.motor_matrix(), dtype=float).reshape(nj, nu)
             for k, v in enumerate(S.reshape(-1)):
                 m.S[k] = v
-        costs = self.costs.lower(nj, nx, nu)
+        costs = self.costs.lower(nj, nx, nu, nu_dev)
         m.ncosts = len(costs)
         for i, c in enumerate(costs):
             m.costs[i] = c
@@ -374,7 +390,16 @@ class _DifferentialBase(object):
             for k in range(nu):
                 m.u_lb[k] = float(u_lb[k])
                 m.u_ub[k] = float(u_ub[k])
+            for k in range(nu, nu_dev):
+                m.u_lb[k], m.u_ub[k] = -1.0, 1.0
         return m
+
+    @property
+    def nu_dev(self):
+        """control size of the lowered model (SEA: one command per joint, padded when the actuation has fewer)"""
+        if self.dam == _abi.DAM_SEA:
+            return max(self.nu, self.state.pinocchio.nv)
+        return self.nu
 
     # -- single-point evaluation on the GPU (the path the reference's unit tests exercise) --
     def calc(self, data, x, u=None):

@@ -56,6 +56,14 @@ SPECS = {
                  ("xGoalR", "pendulum", 1e-1, (1, 1, 1, 1, .1, .1))],
         terminal=[("xGoal", "pendulum", 1e4, (1, 1, 1, 1, .1, .1))],
         stiffness=1.0, motor_inertia=1e-3, dt=1e-2, solver="SolverDDP", maxiter=100, th_stop=1e-9, T=100),
+    # the same problem with ActuationModelDoublePendulum(state, actLink=0, nu=1) (python/aslr_to/__init__.py:279-281): ONE
+    # motor command; the control cost then has one weight
+    "double_pendulum_nu1": dict(
+        robot="double_pendulum", gravity=None, actuator="pendulum", pendulum_nu=1, frame=None, target=None,
+        running=[("uReg", "control", 1e-1, (1.0,)), ("xReg", "state", 1e-2, (1.0, 0.0, 1.0, 0.0)),
+                 ("xGoalR", "pendulum", 1e-1, (1, 1, 1, 1, .1, .1))],
+        terminal=[("xGoal", "pendulum", 1e4, (1, 1, 1, 1, .1, .1))],
+        stiffness=1.0, motor_inertia=1e-3, dt=1e-2, solver="SolverDDP", maxiter=100, th_stop=1e-9, T=100),
     # C5: 7-DoF arm + SEA actuation (nx = 28, nu = 7).  No example script in the reference: the model follows
     # unittest/test_asr_free_fwddyn.py:50-56 (default K = 0.1 I, B = 1e-3 I, free_fwddyn_asr.py:12-19) with C2's
     # cost stack and a 7-DoF end-effector target
@@ -105,7 +113,7 @@ def _build(name, B, T, seed):
         actuation = ASRActuation(state)
         nu = actuation.nu
     else:
-        actuation = ActuationModelDoublePendulum(state, actLink=0, nu=2)
+        actuation = ActuationModelDoublePendulum(state, actLink=0, nu=spec.get("pendulum_nu", 2))
         nu = actuation.nu
     frame_id = model.getFrameId(spec["frame"]) if spec["frame"] else None
     stacks = [_cost_stack(spec[k], state, nu, nj, frame_id, spec["target"]) for k in ("running", "terminal")]
@@ -163,6 +171,11 @@ def double_pendulum(T=100):
     return _build("double_pendulum", 1, T, 0)
 
 
+def double_pendulum_nu1(T=100):
+    """C1 with one motor command (nu = 1)."""
+    return _build("double_pendulum_nu1", 1, T, 0)
+
+
 def talos_arm_sea(B=1, T=150, seed=0):
     """C5."""
     return _build("talos_arm_sea", B, T, seed)
@@ -170,7 +183,7 @@ def talos_arm_sea(B=1, T=150, seed=0):
 
 SCENARIOS = {"two_dof_vsa_boxddp": two_dof_vsa_boxddp, "two_dof_vsa_modified": two_dof_vsa_modified,
              "two_dof_sea": two_dof_sea,
-             "double_pendulum": double_pendulum, "talos_arm_sea": talos_arm_sea}
+             "double_pendulum": double_pendulum, "double_pendulum_nu1": double_pendulum_nu1, "talos_arm_sea": talos_arm_sea}
 
 
 def lower(sc):

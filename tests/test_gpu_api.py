@@ -638,3 +638,45 @@ def test_pool_solve_on_the_other_models_and_solvers(name, solver, P, slots, T, m
     assert torch.equal(r["xs"], full.region(_abi.R_XS).permute(1, 0, 2).contiguous())
     assert torch.equal(r["us"], full.region(_abi.R_US).permute(1, 0, 2).contiguous())
     assert torch.equal(r["cost"], full.traj_f(_abi.TF_COST))
+
+
+def test_pendulum_with_one_motor_command_solves_like_the_two_command_model():
+    """ActuationModelDoublePendulum(state, actLink=0, nu=1) (python/aslr_to/__init__.py:279-281) next to the nu = 2 form
+    the C1 scenario uses (second command drives nothing, zero weight): the same xs, the same motor command, the same
+    iteration count -- and every control-sized quantity the solver / the data objects expose has ONE column."""
+    import torch
+    res = {}
+    for name in ("double_pendulum", "double_pendulum_nu1"):
+        sc = scenarios.SCENARIOS[name](T=100)
+        problem = crocoddyl.ShootingProblem(sc["x0"][0], sc["running"], sc["terminal"])
+        solver = crocoddyl.SolverDDP(problem)
+        solver.th_stop = 1e-9
+        solver.solve([], [], 60)
+        torch.cuda.synchronize()
+        res[name] = dict(xs=np.array(solver.xs), us=np.array(solver.us), K=np.array(solver.K), k=np.array(solver.k),
+                         Qu=np.array(solver.Qu), iters=solver.iterations, cost=solver.cost, problem=problem, solver=solver)
+    a, b = res["double_pendulum"], res["double_pendulum_nu1"]
+    assert b["us"].shape == (100, 1) and b["K"].shape == (100, 1, 8) and b["k"].shape == (100, 1) and b["Qu"].shape == (100, 1)
+    assert a["us"].shape == (100, 2) and np.abs(a["us"][:, 1]).max() == 0.0      # the idle command of the nu = 2 form stays at zero
+    assert a["iters"] == b["iters"]
+    np.testing.assert_allclose(b["xs"], a["xs"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(b["us"][:, 0], a["us"][:, 0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(b["K"][:, 0], a["K"][:, 0], rtol=0, atol=1e-7 * (1 + np.abs(a["K"]).max()))
+    assert abs(a["cost"] - b["cost"]) < 1e-9 * max(1.0, abs(a["cost"]))
+    # warm start with nu = 1 controls, node data, model-level calc / calcDiff
+    p = b["problem"]
+    c = p.calc(list(b["xs"]), list(b["us"]))
+    assert abs(c - b["cost"]) < 1e-8 * max(1.0, abs(c))
+    p.calcDiff(list(b["xs"]), list(b["us"]))
+    d = p.runningDatas[3]
+    assert d.Fu.shape == (8, 1) and d.Lu.shape == (1,) and d.Luu.shape == (1, 1) and d.Lxu.shape == (8, 1)
+    pa = a["problem"]
+    pa.calcDiff(list(a["xs"]), list(a["us"]))
+    np.testing.assert_allclose(d.Fu[:, 0], pa.runningDatas[3].Fu[:, 0], rtol=0, atol=1e-9)
+    m = p.runningModels[0]
+    data = m.createData()
+    m.calc(data, b["xs"][5], b["us"][5])
+    m.calcDiff(data, b["xs"][5], b["us"][5])
+    assert data.Fu.shape == (8, 1) and np.isfinite(data.Fu).all() and data.r.shape[0] == m.nr
+    roll = p.rollout(list(b["us"]))
+    np.testing.assert_allclose(np.array(roll), b["xs"], rtol=0, atol=1e-8)

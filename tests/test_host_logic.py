@@ -58,6 +58,7 @@ def test_workspace_size_is_the_sum_of_the_documented_regions():
     doubles = ((T + 1) * B * nx * 5 + T * B * nu * 3 + (T + 1) * B + (T + 1) * B * rec + T * B * nu * nx
                + (T + 1) * B * nx * nx + 10 * (T + 1) * B * nx + 10 * T * B * nu + _abi.TF_COUNT * B + B * nx + B * 12)
     doubles += 10 * (T + 1) * B  # COST_TRY
+    doubles += B * (nx + 12)     # POOL_SAVE
     assert doubles * 8 <= n <= doubles * 8 + 64 * 1024
     bad = scenarios.lower(sc)
     bad.desc.B = 0
@@ -221,3 +222,18 @@ def test_parity_report_names_the_first_differing_decision():
         _parity.assert_status_words_match(np.array([1, 1, 1, 2]), np.array([1, 1, 3, 2]))
     with pytest.raises(AssertionError):
         _parity.assert_status_words_match(np.array([9, 9, 1, 2]), np.array([1, 1, 1, 2]))
+
+
+def test_one_motor_command_pendulum_is_lowered_with_padded_controls():
+    """ActuationModelDoublePendulum(state, actLink=0, nu=1) (python/aslr_to/__init__.py:279-281): the model keeps nu = 1
+    for its user; the lowered description carries nu = nj = 2 with a zero second column of S, a unit weight on the padded
+    command in the control cost, and the same first column / weight as the nu = 2 lowering of the same problem."""
+    lo1, lo2 = scenarios.lower(scenarios.double_pendulum_nu1(T=5)), scenarios.lower(scenarios.double_pendulum(T=5))
+    assert (lo1.nu_user, lo1.nu, lo2.nu_user, lo2.nu) == (1, 2, 2, 2)
+    m1, m2 = lo1.desc.models[0], lo2.desc.models[0]
+    assert m1.nu == 2 and list(m1.S[:4]) == [1.0, 0.0, 0.0, 0.0] and list(m2.S[:4]) == [1.0, 0.0, 0.0, 0.0]
+    c1 = [c for c in m1.costs[:m1.ncosts] if c.type == _abi.COST_CONTROL][0]
+    c2 = [c for c in m2.costs[:m2.ncosts] if c.type == _abi.COST_CONTROL][0]
+    assert list(c1.act_w[:2]) == [1.0, 1.0] and list(c2.act_w[:2]) == [1.0, 0.0] and c1.weight == c2.weight
+    sc = scenarios.double_pendulum_nu1(T=5)
+    assert sc["running"][0].nu == 1 and sc["running"][0].differential.nu_dev == 2
