@@ -155,6 +155,77 @@ ASLR_DEV bool boxqp(const double (&H)[NU][NU], const double (&q)[NU], const doub
   return bad;
 }
 
+// SolverDDP / SolverBoxDDP computeGains of one knot on register arrays, every lane of the wave running the same problem
+// or its team's (the per-lane form the nu != 4 kernels use; aslr_team_gains.hpp is the lane-distributed form for nu = 4).
+// In: Quu (regularised), qu, the lane's column of Qux in Kc; for a boxed node lb / ub (bounds minus u) and the stored k
+// as warm start k0.  Out: kv = k, Kc = the lane's column of K, qu with clamped entries zeroed.  Returns "backward_error".
+// Box nodes replay BoxQP's first iteration (clamped warm start, gradient, active set); with nothing clamped there the
+// two cheap outcomes -- (a) |g|_inf <= th_grad: x0 itself, (b) the Newton point strictly inside the box -- need only the
+// plain gains; everything else runs boxqp<NU>.
+template <int NU>
+ASLR_DEV bool lane_gains(const double (&Quu)[NU][NU], double (&qu)[NU], double (&Kc)[NU], double (&kv)[NU], bool boxed,
+                         const double (&lb)[NU], const double (&ub)[NU], const double (&k0)[NU], const SolverDev &sp
+#ifdef ASLR_BWD_PROFILE
+                         , long long (&prof_acc)[20], long long &prof_last
+#endif
+                         ) {
+  bool failed = false;
+  double x0[NU], g0[NU], Qux[NU];
+  bool any_clamped = false;
+  double gnorm0 = 0.0;
+  ASLR_UNROLL for (int c = 0; c < NU; ++c) { Qux[c] = Kc[c]; x0[c] = 0.0; g0[c] = 0.0; }
+  if (boxed) {
+    ASLR_UNROLL for (int c = 0; c < NU; ++c) x0[c] = fmax(fmin(k0[c], ub[c]), lb[c]);
+    ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+      double sg = qu[c];
+      ASLR_UNROLL for (int e = 0; e < NU; ++e) sg += Quu[c][e] * x0[e];
+      g0[c] = sg;
+      any_clamped = any_clamped | ((x0[c] == lb[c]) & (sg > 0.0)) | ((x0[c] == ub[c]) & (sg < 0.0));
+      gnorm0 = fmax(gnorm0, fabs(sg));
+    }
+  }
+  const bool need_plain = !boxed || !any_clamped;
+  bool plain_bad = false;
+  ASLR_UNROLL for (int c = 0; c < NU; ++c) { kv[c] = 0.0; Kc[c] = 0.0; }
+  if (__ballot(need_plain) != 0ull) {
+    double L[NU][NU], rinv[NU];
+    ASLR_UNROLL for (int c = 0; c < NU; ++c)
+      ASLR_UNROLL for (int e = 0; e < NU; ++e) L[c][e] = Quu[c][e];
+    plain_bad = chol_rs<NU>(L, rinv);
+    ASLR_UNROLL for (int c = 0; c < NU; ++c) { kv[c] = qu[c]; Kc[c] = Qux[c]; }
+    chol_solve_r<NU>(L, rinv, kv);
+    chol_solve_r<NU>(L, rinv, Kc);
+  }
+  if (!boxed) {
+    if (plain_bad) failed = true;
+  } else {
+    bool interior = !any_clamped && !plain_bad && sp.boxqp_reg == 0.0;
+    ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+      const double dlt = -kv[c], mrg = 1e-9 * (1.0 + fabs(dlt));
+      interior = interior & (dlt > lb[c] + mrg) & (dlt < ub[c] - mrg);
+    }
+    if (!any_clamped && !plain_bad && sp.boxqp_reg == 0.0 && gnorm0 <= sp.boxqp_th_grad) {
+      ASLR_UNROLL for (int c = 0; c < NU; ++c) kv[c] = -x0[c]; // (a)
+    } else if (interior) {
+      // (b): kv, Kc already hold the result
+    } else {
+      double xq[NU];
+      bool cm[NU];
+      ASLR_UNROLL for (int c = 0; c < NU; ++c) { xq[c] = x0[c]; Kc[c] = Qux[c]; }
+      if (boxqp<NU>(Quu, qu, lb, ub, xq, g0, cm, Kc, sp.boxqp_maxiter, sp.boxqp_th_acceptstep, sp.boxqp_th_grad, sp.boxqp_reg
+#ifdef ASLR_BWD_PROFILE
+                    , prof_acc, prof_last
+#endif
+                    )) failed = true;
+      ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+        kv[c] = -xq[c];
+        if (cm[c]) qu[c] = 0.0;
+      }
+    }
+  }
+  return failed;
+}
+
 // TPWA: teams actually used per wave (<= 64 / TEAM).  Fewer teams per wave means more waves (idle issue
 // slots are plentiful at 4096 trajectories per GPU) and less lock-step waste in the per-team BoxQP loops.
 template <int NX, int NU, int HS, int TPWA = 0>

@@ -17,7 +17,9 @@
 //   * Vxx = Qxx - Qux^T K, its symmetrisation and the NaN / 1e30 test are again one row x 4 columns per thread;
 //   * the next knot's record (16 KB) is prefetched into registers (8 x 16 B per thread) during the knot.
 //
-// Box constraints are not handled here: a SolverBoxDDP problem of this size takes backward_kernel.
+// SolverBoxDDP (BOX): wave 0 also runs computeGains' box QP for the block's trajectory (lane_gains<NU>: every lane the
+// same nu x nu problem, wave-uniform control flow, the lane's own column of Qux solved with the final free-set factor);
+// the node's u and stored k (the QP's bounds and warm start) come in with the record prefetch.
 #pragma once
 #include "aslr_backward.inc.hpp"
 
@@ -39,7 +41,7 @@ struct BwdBlk {
   static constexpr int sRec = 0, sPT = sRec + even(REC), sVx = sPT + NX * NX, sA = sVx + even(NX), sB = sA + NX * NX,
                        sQux = sB + even(NU * NX), sQuxT = sQux + even(NU * NX), sK = sQuxT + NX * 8,
                        sQuu = sK + 8 * NX, sQu = sQuu + 64, sQx = sQu + 8, sF = sQx + 32,
-                       sRed = sF + 32, sCost = sRed + 64, sFlag = sCost + NT, sEnd = sFlag + 2;
+                       sRed = sF + 32, sCost = sRed + 64, sFlag = sCost + NT, sUK = sFlag + 2, sEnd = sUK + 16;
   static constexpr int LDS = even(sEnd);
 };
 
@@ -50,8 +52,8 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // column l & 15).  The instruction accumulates exactly like the k-ordered fma chain of the vector path
 // (tools/ubench/mfma_f64_layout.hip: 256 / 256 entries bit-equal), so both paths give the same bits.  It has the
 // vector unit's FP64 rate; what it saves is issue slots: 35 MFMAs per wave and knot replace 504 FMAs + 196 LDS reads.
-template <int NX, int NU, bool GAPS, bool MFMA>
-__global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp) {
+template <int NX, int NU, bool GAPS, bool MFMA, bool BOX = false>
+__global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
   using C = BwdBlk<NX, NU>;
   constexpr int REC = C::REC, NG = C::NG, NT = C::NT;
   __shared__ double sm[C::LDS];
@@ -59,6 +61,7 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
          *QuxT = sm + C::sQuxT, *KL = sm + C::sK, *QuuL = sm + C::sQuu, *QuL = sm + C::sQu, *QxL = sm + C::sQx,
          *VxL = sm + C::sVx, *FL = sm + C::sF, *RedL = sm + C::sRed, *CostL = sm + C::sCost;
   int *FlagL = reinterpret_cast<int *>(sm + C::sFlag);
+  double *UKL = sm + C::sUK; // [u (8) | stored k (8)] of the knot (box nodes)
 
   const int tid = threadIdx.x, rr = tid >> 3, g = tid & 7;
   const int gc = g < NG ? g : NG - 1, gu = g < NU ? g : NU - 1;
@@ -108,6 +111,7 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
   double xreg = TF[ASLR_TF_XREG * B + b];
   const bool fddp = GAPS && sp.solver == ASLR_SOLVER_FDDP;
   const bool gaps_on = GAPS && !feasible;
+  const bool box = BOX && sp.solver == ASLR_SOLVER_BOXDDP && feasible; // (SolverBoxDDP::computeGains: plain gains while infeasible)
 
   // pass-2b tasks: entries e of [Qux (nu x nx) | Quu (nu x nu)], e = tid and tid + NT (compile-time strides on
   // each path: a per-thread stride makes the compiler keep one LDS address per contraction step)
@@ -156,7 +160,8 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
       if (tid < NX) VxL[tid] = Vx_own;
     }
     // ---- prefetch of knot T-1 ----
-    double prx[C::NPRE], pry[C::NPRE], pre_f = 0.0;
+    double prx[C::NPRE], pry[C::NPRE], pre_f = 0.0, pre_uk = 0.0;
+    int pre_m = 0;
 #define ASLR_BLK_PREFETCH(tt)                                                                          \
     do {                                                                                               \
       const size_t tbp = (size_t)(tt) * B + b;                                                         \
@@ -167,6 +172,8 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
         if (C::NPRE * NT == REC / 2 || idx < REC / 2) { const nt_double2 v2 = __builtin_nontemporal_load(src + idx); prx[q] = v2.x; pry[q] = v2.y; } \
       }                                                                                                \
       if (gaps_on && tid < NX) pre_f = a.gaps[tbp * NX + tid];                                         \
+      if (box && tid < 16) pre_uk = (tid & 7) < NU ? (tid < 8 ? a.us[tbp * NU + tid] : a.kff[tbp * NU + tid - 8]) : 0.0; \
+      pre_m = node_model_at(a, tt);                                                                    \
     } while (0)
     ASLR_PROF_DECL;
     ASLR_BLK_PREFETCH(T - 1);
@@ -182,7 +189,9 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
           if (C::NPRE * NT == REC / 2 || idx < REC / 2) { double2 v2; v2.x = prx[q]; v2.y = pry[q]; dst[idx] = v2; }
         }
         if (gaps_on && tid < NX) FL[tid] = pre_f;
+        if (box && tid < 16) UKL[tid] = pre_uk;
       }
+      const int mi = pre_m;
       __syncthreads();
       ASLR_PROF(0);
       if (t > 0) ASLR_BLK_PREFETCH(t - 1);
@@ -352,14 +361,34 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
       ASLR_PROF(3);
       // ---- gains (wave 0): K = Quu^-1 Qux (one column per lane), k = Quu^-1 Qu, Quu k, Vx, d1, d2, stop ----
       if (wave0) {
-        double L[NU][NU], rinv[NU], qu[NU], kv[NU], Kc[NU], Quuk[NU];
-        ASLR_UNROLL for (int c = 0; c < NU; ++c) // (chol_rs reads the lower triangle only)
-          ASLR_UNROLL for (int e = 0; e < NU; ++e) L[c][e] = e <= c ? QuuL[c * NU + e] : 0.0;
-        const bool bad = chol_rs<NU>(L, rinv);
+        double qu[NU], kv[NU], Kc[NU], Quuk[NU];
         const int col = tid < NX ? tid : NX - 1;
-        ASLR_UNROLL for (int c = 0; c < NU; ++c) { qu[c] = QuL[c]; kv[c] = qu[c]; Kc[c] = QuxL[c * NX + col]; }
-        chol_solve_r<NU>(L, rinv, kv);
-        chol_solve_r<NU>(L, rinv, Kc);
+        bool bad;
+        const bool boxed = BOX && box && lim.has[mi]; // block-uniform
+        if (BOX && boxed) {
+          double Quu[NU][NU], lb[NU], ub[NU], k0[NU];
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) {
+            ASLR_UNROLL for (int e = 0; e < NU; ++e) Quu[c][e] = QuuL[c * NU + e];
+            qu[c] = QuL[c]; Kc[c] = QuxL[c * NX + col];
+            const double ut = UKL[c];
+            k0[c] = UKL[8 + c];
+            lb[c] = lim.lb[mi][c] - ut;
+            ub[c] = lim.ub[mi][c] - ut;
+          }
+#ifdef ASLR_BWD_PROFILE
+          bad = lane_gains<NU>(Quu, qu, Kc, kv, true, lb, ub, k0, sp, prof_acc, prof_last);
+#else
+          bad = lane_gains<NU>(Quu, qu, Kc, kv, true, lb, ub, k0, sp);
+#endif
+        } else {
+          double L[NU][NU], rinv[NU];
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) // (chol_rs reads the lower triangle only)
+            ASLR_UNROLL for (int e = 0; e < NU; ++e) L[c][e] = e <= c ? QuuL[c * NU + e] : 0.0;
+          bad = chol_rs<NU>(L, rinv);
+          ASLR_UNROLL for (int c = 0; c < NU; ++c) { qu[c] = QuL[c]; kv[c] = qu[c]; Kc[c] = QuxL[c * NX + col]; }
+          chol_solve_r<NU>(L, rinv, kv);
+          chol_solve_r<NU>(L, rinv, Kc);
+        }
         ASLR_UNROLL for (int c = 0; c < NU; ++c) {
           double s = 0.0;
           ASLR_UNROLL for (int e = 0; e < NU; ++e) s += QuuL[c * NU + e] * kv[e];
@@ -524,17 +553,20 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
 }
 
 template <int NX, int NU>
-int launch_backward_blk(const KArgs &k, const SolverDev &sd, bool all_feasible, hipStream_t st) {
+int launch_backward_blk(const KArgs &k, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st) {
   // ASLR_BLK_MFMA=0 selects the vector-FMA products (comparison runs; both paths give the same bits)
   const char *e = getenv("ASLR_BLK_MFMA");
   const bool mfma = e ? atoi(e) != 0 : true;
   const dim3 grid(k.b1 - k.b0), block(BwdBlk<NX, NU>::NT);
-  if (mfma) {
-    if (all_feasible) hipLaunchKernelGGL((backward_blk_kernel<NX, NU, false, true>), grid, block, 0, st, k, sd);
-    else hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true, true>), grid, block, 0, st, k, sd);
+  if (sd.solver == ASLR_SOLVER_BOXDDP) { // (gap terms compiled in: a cold-started BoxDDP solve is infeasible at first)
+    if (mfma) hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true, true, true>), grid, block, 0, st, k, sd, lim);
+    else hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true, false, true>), grid, block, 0, st, k, sd, lim);
+  } else if (mfma) {
+    if (all_feasible) hipLaunchKernelGGL((backward_blk_kernel<NX, NU, false, true>), grid, block, 0, st, k, sd, lim);
+    else hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true, true>), grid, block, 0, st, k, sd, lim);
   } else {
-    if (all_feasible) hipLaunchKernelGGL((backward_blk_kernel<NX, NU, false, false>), grid, block, 0, st, k, sd);
-    else hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true, false>), grid, block, 0, st, k, sd);
+    if (all_feasible) hipLaunchKernelGGL((backward_blk_kernel<NX, NU, false, false>), grid, block, 0, st, k, sd, lim);
+    else hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true, false>), grid, block, 0, st, k, sd, lim);
   }
   HIP_TRY(hipGetLastError());
   return ASLR_OK;

@@ -169,6 +169,78 @@ SOLVE_CASES = [
 ]
 
 
+def _with_box(sc, lb, ub):
+    """the scenario's running model with control limits (-> has_control_limits, SolverBoxDDP's QP at every knot)"""
+    sc = dict(sc)
+    sc["running"][0].u_lb = np.full(sc["running"][0].nu, float(lb))
+    sc["running"][0].u_ub = np.full(sc["running"][0].nu, float(ub))
+    return sc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hs", [0, 2])
+def test_boxddp_on_the_seven_joint_arm_matches_oracle(oracle, monkeypatch, hs):
+    """SolverBoxDDP at nx = 28 / nu = 7 (north_star: batched DDP / BoxDDP; config 5's model): motor commands boxed tightly
+    enough that the QP clamps at many knots.  hs = 0: the block-per-trajectory kernel with the box QP in its gains phase
+    (the default since round 3); hs = 2: the register-column kernel it replaces.  Backward pass from identical inputs
+    against the oracle, then full solves with the oracle's iteration counts."""
+    import torch
+    if hs:
+        monkeypatch.setenv("ASLR_BWD_HS", str(hs))
+    else:
+        monkeypatch.delenv("ASLR_BWD_HS", raising=False)
+    sc = _with_box(scenarios.talos_arm_sea(B=5, T=12, seed=2), -0.6, 0.6)
+    low = scenarios.lower(sc)
+    sp = scenarios.solver_params(sc, solver="SolverBoxDDP")
+    e = _engine(low)
+    xs, us, deriv, gaps = _backward_inputs(oracle, low, 3)
+    us = np.clip(us, -0.6, 0.6)
+    rng = np.random.default_rng(5)
+    k0 = rng.uniform(-0.5, 0.5, us.shape)       # stored k = the QP's warm start
+    xreg = 1e-3
+    e.region(_abi.R_US).copy_(torch.as_tensor(us))
+    e.region(_abi.R_DERIV).copy_(torch.as_tensor(deriv))
+    e.region(_abi.R_GAPS).zero_()
+    e.region(_abi.R_KFF).copy_(torch.as_tensor(k0))
+    e.region(_abi.R_TRAJ_F)[_abi.TF_XREG].fill_(xreg)
+    e.region(_abi.R_TRAJ_I)[_abi.TI_FEASIBLE].fill_(1)
+    e.region(_abi.R_TRAJ_I)[_abi.TI_STATUS].fill_(0)
+    e.backward_pass(sp)
+    _sync()
+    ref = oracle.backward_pass(low, sp, deriv, np.zeros_like(gaps), us, xreg, 1, kff0=k0)
+    assert not ref["fail"].any()
+    assert (_np(e.traj_i(_abi.TI_STATUS)) & _abi.ST_BACKWARD_ERR == 0).all()
+    clamped = (ref["Qu"] == 0.0).mean()
+    assert 0.05 < clamped < 0.95, clamped       # the box is really active at a share of the (knot, control) pairs
+    tol = 1e-8
+    assert _relerr(_np(e.region(_abi.R_KGAIN)), ref["K"]) < tol
+    assert _relerr(_np(e.region(_abi.R_KFF)), ref["k"]) < tol
+    assert _relerr(_np(e.region(_abi.R_QU)), ref["Qu"]) < tol
+    assert _relerr(_np(e.region(_abi.R_VX)), ref["Vx"]) < tol
+    assert _relerr(_np(e.region(_abi.R_VXX)), ref["Vxx"]) < tol
+    for fld, name in ((_abi.TF_D1, "d1"), (_abi.TF_D2, "d2"), (_abi.TF_STOP, "stop")):
+        assert _relerr(_np(e.traj_f(fld)), ref[name]) < tol
+    # full solves
+    sc2 = _with_box(scenarios.talos_arm_sea(B=3, T=30, seed=4), -1.0, 1.0)
+    low2 = scenarios.lower(sc2)
+    sp2 = scenarios.solver_params(sc2, solver="SolverBoxDDP", maxiter=40)
+    ref2 = oracle.solve(low2, sp2)
+    e2 = _engine(low2)
+    e2.set_candidate(None, None)
+    e2.solve(sp2, poll_every=4)
+    _sync()
+    np.testing.assert_array_equal(_np(e2.traj_i(_abi.TI_ITER)), ref2["traj_i"][_abi.TI_ITER])
+    import _parity
+    _parity.assert_status_words_match(_np(e2.traj_i(_abi.TI_STATUS)), ref2["traj_i"][_abi.TI_STATUS])
+    U = _np(e2.region(_abi.R_US))
+    assert U.min() >= -1.0 and U.max() <= 1.0 and (np.abs(U) == 1.0).any()    # the solution rides the bounds somewhere
+    dx = np.abs(_np(e2.region(_abi.R_XS)) - ref2["xs"]).max()
+    du = np.abs(U - ref2["us"]).max()
+    dc = np.abs(_np(e2.traj_f(_abi.TF_COST)) - ref2["traj_f"][_abi.TF_COST]).max()
+    print("7-joint BoxDDP hs=%d: iterations %s, dx %.2e du %.2e dcost %.2e" % (hs, ref2["traj_i"][_abi.TI_ITER], dx, du, dc))
+    assert dx < 1e-6 and du < 1e-6 and dc < 1e-4
+
+
 @pytest.mark.parametrize("name,kw,solver", SOLVE_CASES)
 def test_solve_matches_oracle(oracle, name, kw, solver):
     """north_star: xs/us within 1e-6, final cost within 1e-4 of the CPU solver on identical inputs."""

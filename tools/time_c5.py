@@ -4,6 +4,10 @@ from aslr_to_amd import scenarios, _abi as A
 from aslr_to_amd.engine import Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 sc = scenarios.talos_arm_sea(B=B, T=150)
+if len(sys.argv) > 2 and sys.argv[2] == "SolverBoxDDP":   # motor commands boxed: the QP runs at every knot
+    lim = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0
+    sc["running"][0].u_lb = np.full(7, -lim)
+    sc["running"][0].u_ub = np.full(7, lim)
 low = scenarios.lower(sc)
 e = Engine(low)
 e.set_candidate(None, None)
