@@ -58,7 +58,7 @@ WORKLOADS = {
                metric="knot-steps/s (batched DDP, 7-DoF arm + SEA, T=150, 512 trajectories per GPU = 4096 over 8 GPUs)",
                what="talos_arm_sea (7-joint chain with SEA actuation, cost stack of examples/two_dof_sea.py, T=150): SolverDDP, "
                     "cold start, fixed-iteration mode, full 10-alpha line search every iteration",
-               kernels=["dyn_team_kernel<7, 1>", "backward_blk_kernel<28, 7, true>", "rollout_team_kernel<7, 0, false>"],
+               kernels=["dyn_team_kernel<7, 1>", "backward_blk_kernel<28, 7, true, true, false>", "rollout_team_kernel<7, false>"],
                cpu=dict(per_thread=8, single=8, maxiter=30)),
 }
 
