@@ -328,6 +328,14 @@ class SolverDDP(object):
         return [1.0 / 2 ** j for j in range(_abi.NALPHA)]
 
     def setCallbacks(self, callbacks):
+        """Callbacks are NOT called during the solve: the line-search kernel records what they read (cost, stop, regularisation,
+        step length, d, dV, feasibility, status) into a device-resident log and they are replayed from it when solve()
+        returns (B = 1: once per iteration with an _IterationView; a batch: `from_batch_log`).  Consequences, different
+        from Crocoddyl: (1) inside a callback `xs / us / fs / K / k` are the solver's FINAL values, not those of that
+        iteration (a display callback such as examples/double_pendulum.py:60 CallbackDisplay would show the final
+        trajectory every time); (2) CallbackVerbose prints after the solve, not while it runs; (3) a callback cannot
+        stop the solve.  For per-iteration trajectories drive the solver one iteration at a time: `solve(xs, us, 1,
+        isFeasible=...)` in a loop keeps every semantic of the reference at the price of a host round trip per iteration."""
         self._callbacks = list(callbacks)
 
     def getCallbacks(self):

@@ -135,6 +135,7 @@ struct aslr_problem {
   aslr_region_t regions[ASLR_R_COUNT];
   KArgs k;
   int32_t *h_done; // pinned staging for count_active
+  int bwd_hs, blk_mfma; // launch-path switches (ASLR_BWD_HS, ASLR_BLK_MFMA), read from the environment at create time
   hipEvent_t ev[4];
   bool have_ev;
   // sub-shards (aslr_set_subshards): contiguous trajectory ranges [sub_b[s], sub_b[s + 1]) iterated on their own
@@ -354,9 +355,8 @@ ModelLimits make_limits(const aslr_problem *p) {
 
 int backward_hs(const aslr_problem *p) {
   // 0: each size picks its default decomposition; ASLR_BWD_HS forces the register-column kernel with that
-  // many lanes per column (tests and comparisons)
-  const char *e = getenv("ASLR_BWD_HS");
-  return e ? atoi(e) : 0;
+  // many lanes per column (tests and comparisons).  Read once, when the handle is created.
+  return p->bwd_hs;
 }
 
 // nj = 7 with VSA actuation (nx = 28, nu = 14) is built at the MODEL level only -- calc / calcDiff sweeps, dam_eval,
@@ -375,7 +375,7 @@ int launch_backward(aslr_problem *p, const SolverDev &sd, hipStream_t st, bool a
   const int hs = backward_hs(p);
   const ModelLimits lim = make_limits(p);
   if (p->nx == 8) return launch_backward_nx8(p->k, p->nu, hs, sd, lim, all_feasible, st);
-  if (p->nx == 28) return launch_backward_nx28(p->k, p->nu, hs, sd, lim, all_feasible, st);
+  if (p->nx == 28) return launch_backward_nx28(p->k, p->nu, (hs == 0 && !p->blk_mfma) ? -1 : hs, sd, lim, all_feasible, st);
   snprintf(g_err, sizeof g_err, "unsupported (nx=%d, nu=%d)", p->nx, p->nu);
   return ASLR_E_INVALID;
 }
@@ -457,6 +457,11 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { snprintf(g_err, sizeof g_err, "no HIP device"); return ASLR_E_NODEVICE; }
   aslr_problem *p = new (std::nothrow) aslr_problem();
+  if (p) {
+    const char *eh = getenv("ASLR_BWD_HS"), *em = getenv("ASLR_BLK_MFMA");
+    p->bwd_hs = eh ? atoi(eh) : 0;
+    p->blk_mfma = em ? (atoi(em) != 0) : 1;
+  }
   if (!p) return ASLR_E_INVALID;
   p->desc = *desc;
   p->desc.node_model = nullptr; p->desc.x0 = nullptr; p->desc.frame_ref = nullptr;

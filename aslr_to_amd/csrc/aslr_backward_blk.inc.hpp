@@ -553,10 +553,9 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
 }
 
 template <int NX, int NU>
-int launch_backward_blk(const KArgs &k, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st) {
-  // ASLR_BLK_MFMA=0 selects the vector-FMA products (comparison runs; both paths give the same bits)
-  const char *e = getenv("ASLR_BLK_MFMA");
-  const bool mfma = e ? atoi(e) != 0 : true;
+int launch_backward_blk(const KArgs &k, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, bool mfma, hipStream_t st) {
+  // mfma = false (ASLR_BLK_MFMA=0 when the handle was created) selects the vector-FMA products (comparison runs; both
+  // paths give the same bits)
   const dim3 grid(k.b1 - k.b0), block(BwdBlk<NX, NU>::NT);
   if (sd.solver == ASLR_SOLVER_BOXDDP) { // (gap terms compiled in: a cold-started BoxDDP solve is infeasible at first)
     if (mfma) hipLaunchKernelGGL((backward_blk_kernel<NX, NU, true, true, true>), grid, block, 0, st, k, sd, lim);

@@ -6,7 +6,7 @@ namespace aslr {
 //     1 / 2 = force the register-column kernel with that many lanes per column (tests, comparisons)
 int launch_backward_nx28(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st) {
   if (nu == 7) {
-    if (hs == 0) return launch_backward_blk<28, 7>(k, sd, lim, all_feasible, st);
+    if (hs <= 0) return launch_backward_blk<28, 7>(k, sd, lim, all_feasible, hs == 0, st); // (-1: vector-FMA products)
     if (hs == 0) hs = k.B <= 8192 ? 2 : 1;
     return hs == 2 ? launch_backward_t<28, 7, 2>(k, sd, lim, all_feasible, st) : launch_backward_t<28, 7, 1>(k, sd, lim, all_feasible, st);
   }

@@ -2,7 +2,7 @@
 
 PyTorch-ROCm is used for storage and streams only: ONE torch uint8 tensor is the workspace the HIP
 library carves into regions; every region is exposed as a zero-copy typed torch view.  All
-arithmetic happens in the hand-written HIP kernels (csrc/aslr_kernels.hip).  No CPU fallback: if the
+arithmetic happens in the hand-written HIP kernels (csrc/aslr_*.hip: one translation unit per kernel family and size).  No CPU fallback: if the
 library or a GPU is missing this module raises.
 """
 import ctypes as C
