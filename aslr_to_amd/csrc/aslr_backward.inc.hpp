@@ -829,7 +829,7 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : (BwdCfg<NX, NU
   if (C::TEAMQP && threadIdx.x == 0) { // team-gains regions 1..5 -> table entries 6..9 (+ 5 stays the total), counters 10..12 -> 13, 12, 14
     long long *g = tg_prof();
     prof_acc[6] += g[1]; prof_acc[7] += g[2]; prof_acc[8] += g[3]; prof_acc[9] += g[4] + g[5];
-    prof_acc[13] += g[10]; prof_acc[12] += g[11]; prof_acc[14] += g[12];
+    prof_acc[13] += g[10]; prof_acc[12] += g[11]; prof_acc[14] += g[12]; prof_acc[17] += g[13];
   }
 #endif
   ASLR_PROF_FLUSH;

@@ -199,6 +199,7 @@ ASLR_TG_FN void team_gains4(const typename O::real (&Hr)[4], typename O::real q,
       mask found = finished | cbad;
       real alpha = one, fnext = fold;
       for (int al = 0; al < P.nalpha; ++al) {
+        ASLR_TG_COUNT(13);
         const real xn = O::fmax(O::fmin(x + alpha * dx, ub), lb);
         real s = zero;
         O::template matvec_acc<false>(s, xn, Hr);

@@ -18,10 +18,11 @@ e.set_candidate(None, None)
 sp = scenarios.solver_params(sc, solver=solver, fixed_iterations=1)
 lib = A.load_library()
 out = (ctypes.c_ulonglong * 32)()
-for i in range(20): e.iterate(sp, i == 0)
+WARM = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+for i in range(WARM): e.iterate(sp, i == 0)
 torch.cuda.synchronize()
 lib.aslr_debug_bwd_prof(out, 1)
-N = 30
+N = int(sys.argv[4]) if len(sys.argv) > 4 else 30
 for i in range(N): e.iterate(sp, False)
 torch.cuda.synchronize()
 lib.aslr_debug_bwd_prof(out, 0)
@@ -39,3 +40,5 @@ print("wave-knots %d, cycles per wave-knot %.0f" % (knots, tot / knots))
 for n, c in zip(names, v[:13]): print("  %-32s %8.0f cycles  %5.1f %%" % (n, c / knots, 100 * c / tot))
 print("  (old per-lane QP: QP calls per wave-knot, iterations per call, plain executions per wave-knot;\n   team gains: wave-knots that enter the QP loop, line searches per entry, final re-factorisations per wave-knot)\n  %.3f, %.3f, %.3f"
       % (v[17] / knots, v[16] / max(v[17], 1), v[18] / knots))
+raw = np.array(list(out), dtype=np.float64)
+print("  step lengths tried per line search: %.3f" % (raw[17] / max(raw[12], 1)))
