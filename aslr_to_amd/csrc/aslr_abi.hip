@@ -51,8 +51,16 @@ __global__ void __launch_bounds__(64) pool_refill_kernel(KArgs a, PoolDev pl, do
   const int j = pl.slot_problem[b];
   if (tid == 0) { // one thread decides for the block (other blocks bump the counter during this launch)
     const int done = TI[ASLR_TI_DONE * B + b];
-    skip = (j >= 0 && !done)                                                      // still iterating
-           || (j < 0 && __atomic_load_n(&pl.counters[0], __ATOMIC_RELAXED) >= pl.P); // idle, nothing left to hand out (the counter only grows)
+    skip = j >= 0 && !done; // still iterating
+    if (j < 0 && __atomic_load_n(&pl.counters[0], __ATOMIC_RELAXED) >= pl.P) {
+      // idle and nothing left to hand out (the counter only grows).  The slot must still be MARKED idle: in the first
+      // launch of a pool smaller than the slot count a late block sees the counter past P before it has ever run, and a
+      // slot left with DONE = 0 would be iterated with whatever state the handle held (on a fresh handle x_reg = 0: a
+      // backward sweep that fails and cannot raise its regularisation)
+      TI[ASLR_TI_DONE * B + b] = 1;
+      TI[ASLR_TI_ACCEPTED * B + b] = -1;
+      skip = 1;
+    }
   }
   __syncthreads();
   if (skip) return;

@@ -810,9 +810,12 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : (BwdCfg<NX, NU
           if (lt == 0) TI[ASLR_TI_STATUS * B + b] = status;
           need = false;
         } else {
-          xreg *= sp.reg_incfactor;
+          // (a regularisation that cannot grow -- zero, NaN, a factor <= 1 -- would redo the sweep for ever: Crocoddyl's own
+          //  loop has the same property; here it counts as the ceiling, so that the kernel always terminates)
+          const double grown = xreg * sp.reg_incfactor;
+          xreg = (grown > xreg) ? grown : sp.reg_max;
           if (xreg > sp.reg_max) xreg = sp.reg_max;
-          if (xreg == sp.reg_max) {
+          if (!(xreg < sp.reg_max)) { // (== reg_max; also a NaN ceiling ends the retries)
             status |= ASLR_ST_REG_MAX;
             if (lt == 0) {
               TF[ASLR_TF_XREG * B + b] = xreg;

@@ -536,9 +536,10 @@ __global__ void __launch_bounds__(128) backward_blk_kernel(KArgs a, SolverDev sp
         if (tid == 0) TI[ASLR_TI_STATUS * B + b] = status;
         need = false;
       } else {
-        xreg *= sp.reg_incfactor;
+        const double grown = xreg * sp.reg_incfactor; // (a regularisation that cannot grow counts as the ceiling: the kernel must terminate)
+        xreg = (grown > xreg) ? grown : sp.reg_max;
         if (xreg > sp.reg_max) xreg = sp.reg_max;
-        if (xreg == sp.reg_max) {
+        if (!(xreg < sp.reg_max)) { // (== reg_max; also a NaN ceiling ends the retries)
           status |= ASLR_ST_REG_MAX;
           if (tid == 0) {
             TF[ASLR_TF_XREG * B + b] = xreg;

@@ -43,7 +43,14 @@ struct DevTeamOps {
   static ASLR_DEV real fmin(real a, real b) { return ::fmin(a, b); }
   static ASLR_DEV real fmax(real a, real b) { return ::fmax(a, b); }
   static ASLR_DEV real fabs(real a) { return ::fabs(a); }
-  static ASLR_DEV real rsqrt(real a) { return ::rsqrt(a); }
+  // 1 / sqrt(a) for the Cholesky pivots: v_rsq_f64 and the library's own refinement step (the same six operations, so
+  // the same bits for every positive finite argument) WITHOUT its class test for 0 / inf / NaN inputs (3 instructions
+  // per pivot): a pivot that is not positive is flagged from `d > 0` by the caller and the sweep is redone anyway.
+  static ASLR_DEV real rsqrt(real a) {
+    const real y = __builtin_amdgcn_rsq(a);
+    const real e = fma(y * -a, y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+  }
   template <int C>
   static ASLR_DEV real bc(real v) {
     real r;

@@ -1302,7 +1302,12 @@ static int traj_solve(traj_t *s) {
       if (traj_backward(s)) {
         s->status |= ASLR_ST_BACKWARD_ERR;
         recalc = 0;
-        reg_increase(s);
+        { /* a regularisation that cannot grow (zero, NaN, factor <= 1) would retry for ever, in Crocoddyl too; it counts
+           * as the ceiling here and in the kernels (aslr_backward.inc.hpp), so that both always terminate */
+          const double before = s->xreg;
+          reg_increase(s);
+          if (!(s->xreg > before)) s->xreg = s->ureg = sp->reg_max;
+        }
         if (s->xreg == sp->reg_max) { s->status |= ASLR_ST_REG_MAX; return 0; }
         continue;
       }

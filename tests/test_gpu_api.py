@@ -680,3 +680,38 @@ def test_pendulum_with_one_motor_command_solves_like_the_two_command_model():
     assert data.Fu.shape == (8, 1) and np.isfinite(data.Fu).all() and data.r.shape[0] == m.nr
     roll = p.rollout(list(b["us"]))
     np.testing.assert_allclose(np.array(roll), b["xs"], rtol=0, atol=1e-8)
+
+
+def test_pool_smaller_than_the_slots_on_a_fresh_handle_and_a_regularisation_that_cannot_grow():
+    """Two ways a backward sweep could spin for ever, both found as a hang of the test suite in round 3: (1) a pool with fewer
+    problems than slots on a handle that has never solved anything -- the slots that never receive a problem must be
+    marked idle by the first refill even when their block starts after the counter has passed P (they used to keep
+    DONE = 0 and were iterated with x_reg = 0); (2) reg_init = 0 with an indefinite Quu: the retry loop multiplies the
+    regularisation by reg_incfactor, which never reaches reg_max from zero -- it now counts as the ceiling."""
+    import torch
+    from aslr_to_amd.engine import Engine
+    sc = scenarios.two_dof_vsa_boxddp(B=70, T=5, seed=1)
+    for P, maxiter in ((20, 80), (20, 12), (3, 30)):
+        e = Engine(scenarios.lower(sc))                     # fresh: TRAJ_F / TRAJ_I all zero
+        r = e.solve_pool(sc["x0"][:P], sc["frame_refs"][:P], scenarios.solver_params(sc, maxiter=maxiter))
+        torch.cuda.synchronize()
+        assert int(r["iters"].min()) >= 1 and int(r["iters"].max()) <= maxiter
+        full = Engine(scenarios.lower(dict(sc, x0=sc["x0"][:P], frame_refs=sc["frame_refs"][:P])))
+        full.set_candidate(None, None)
+        full.solve(scenarios.solver_params(sc, maxiter=maxiter), poll_every=4)
+        torch.cuda.synchronize()
+        assert torch.equal(r["iters"], full.traj_i(_abi.TI_ITER)) and torch.equal(r["xs"], full.region(_abi.R_XS).permute(1, 0, 2).contiguous())
+    # (2) a regularisation that cannot grow gives up at once instead of spinning: zero weights everywhere make Quu = 0
+    sc0 = scenarios.two_dof_vsa_boxddp(B=8, T=5, seed=1)
+    for m in (sc0["running"][0], sc0["terminal"]):
+        for name in list(m.differential.costs.costs):
+            m.differential.costs.costs[name].weight = 0.0
+    e = Engine(scenarios.lower(sc0))
+    sp = scenarios.solver_params(sc0, maxiter=5)
+    sp.reg_init = 0.0
+    sp.reg_min = 0.0
+    e.set_candidate(None, None)
+    e.solve(sp, poll_every=1)
+    torch.cuda.synchronize()
+    st = e.traj_i(_abi.TI_STATUS).cpu().numpy()
+    assert ((st & _abi.ST_REG_MAX) != 0).all() and int(e.traj_i(_abi.TI_ITER).max()) <= 5
