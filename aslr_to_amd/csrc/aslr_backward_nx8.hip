@@ -4,9 +4,10 @@
 namespace aslr {
 int launch_backward_nx8(const KArgs &k, int nu, int hs, const SolverDev &sd, const ModelLimits &lim, bool all_feasible, hipStream_t st) {
   // wider teams when the batch cannot fill the chip: 1024 trajectories (C2) are 256 waves with 16 lanes each and 512 with 32
-  // (measured at nu = 2: 148 -> 134 us per sweep); at nu = 4 two 32-lane teams per wave lose to four 16-lane ones (the gains
-  // phase is per-wave work: DESIGN.md 5)
-  if (hs == 0) hs = (nu == 2 && k.b1 - k.b0 <= 2048) ? 4 : (k.B <= 8192 ? 2 : 1);
+  // (measured at nu = 2: 148 -> 134 us per sweep).  At nu = 4 two 32-lane teams per wave win as long as ALL sub-shards
+  // together stay at one wave per SIMD (whole shard <= 2048 trajectories: 345 -> 334 us BoxDDP, 184 -> 161 us DDP at 1024) and
+  // lose beyond (two waves per SIMD: the gains phase is per-wave work)
+  if (hs == 0) hs = ((nu == 2 && k.b1 - k.b0 <= 2048) || k.B <= 2048) ? 4 : (k.B <= 8192 ? 2 : 1);
   if (nu == 2) {
     if (hs == 4) return launch_backward_t<8, 2, 4>(k, sd, lim, all_feasible, st);
     return hs == 2 ? launch_backward_t<8, 2, 2>(k, sd, lim, all_feasible, st) : launch_backward_t<8, 2, 1>(k, sd, lim, all_feasible, st);

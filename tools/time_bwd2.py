@@ -1,8 +1,10 @@
 import sys, os, numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aslr_to_amd import scenarios, _abi as A
+if os.environ.get("ASLR_LIB_OVERRIDE"):  # an experimental build of the library
+    A.lib_path = lambda: os.path.abspath(os.environ["ASLR_LIB_OVERRIDE"])
 from aslr_to_amd.engine import Engine
-B = 4096
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 sc = scenarios.two_dof_vsa_boxddp(B=B, T=100)
 low = scenarios.lower(sc)
 e = Engine(low)
