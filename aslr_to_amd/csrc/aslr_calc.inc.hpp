@@ -25,6 +25,9 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
   constexpr int REC = RL::len;
   __shared__ double sm[64 * kLdsStride];
   __shared__ int act[64];
+  // PRE (large chain): each lane's nj x nj block of Lxx is accumulated here, not in registers (odd stride: the lanes of a
+  // wave hit different banks)
+  __shared__ double lqqL[PRE ? 64 * (NJ * NJ) : 1];
 
   const int lane = threadIdx.x, t = blockIdx.y, B = a.B, T = a.T;
   const int b0 = a.b0 + blockIdx.x * 64, bq = b0 + lane; // (b0: first trajectory of this block)
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
     if (compute) {
       static_for<0, kChunk>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
-        sm[lane * kLdsStride + i] = rec_elem<NJ, NU, c * kChunk + i>(kd, dt);
+        sm[lane * kLdsStride + i] = rec_elem<NJ, NU, c * kChunk + i, PRE>(kd, dt);
       });
     }
     wave_sync();
@@ -190,7 +193,12 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
       ModelRegs<NJ, NU> mr;
       mr.load(dm);
       double xn2[NX], cost2 = 0.0;
-      knot_eval<NJ, DAM, kEvalDiff | kEvalSkipDyn, CH>(cc, mr, dm, fref, x, t < T ? u : nullptr, xn2, cost2, &kd);
+      // x and u are handed over as pointers into the committed trajectory (this lane wrote or read them above), not as the
+      // register copies: the cost terms load the entries they use where they use them, and the 70 registers are free
+      // while the frame-placement Jacobian and Hessian are formed
+      kd.lqq_mem = lqqL + lane * (NJ * NJ);
+      knot_eval<NJ, DAM, kEvalDiff | kEvalSkipDyn | kEvalLqqMem, CH>(cc, mr, dm, fref, *reinterpret_cast<const double (*)[NX]>(a.xs + tb * NX),
+                                                       t < T ? a.us + tb * NU : nullptr, xn2, cost2, &kd);
       a.cost[(size_t)t * B + b] = cost2;
     }
   }

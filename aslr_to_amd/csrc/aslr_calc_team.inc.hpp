@@ -11,8 +11,9 @@
 //   lane  NJ      : the nonlinear effects.
 //
 // Intermediates shared by the team (joint rotations, M, M^-1, the kept sweep) live in LDS.  The results --
-// [xout (2 nj) | M^-1 | dtau/dq | dtau/dv] per knot, region DYN -- are consumed by calc_kernel<..., PRE>, which then
-// only does the small dense products, the cost stack and the record assembly.
+// [xout (2 nj) | M^-1 | the link rows of da_dx = M^-1 [-dtau/dq - K | K | -dtau/dv]] per knot, region DYN (layout:
+// dyn_len_c) -- are consumed by calc_kernel<..., PRE>, which then only does the cost stack and the record assembly and
+// reads each da_dx entry where a record line needs it (nothing of the 3 nj^2 block is held in registers).
 #pragma once
 #include "aslr_forward_team.inc.hpp"
 
@@ -220,15 +221,38 @@ __global__ void __launch_bounds__(64) dyn_team_kernel(KArgs a, int mode) {
     }
   } else {
     // ---- RNEA(q, v, a_link) keeping its intermediates, then the two tangent sweeps of this lane ----
-    if (jl) xoL[c] = out[c]; // link accelerations of phase 0
+    if (jl) {
+      xoL[c] = out[c]; // link accelerations and column c of M^-1 from phase 0
+      ASLR_UNROLL for (int i = 0; i < NJ; ++i) MiL[8 * c + i] = out[2 * NJ + i * NJ + c];
+    }
     wave_sync();
     rnea_keep_lds<NJ>(chc, RL, xT + 2 * NJ, xoL, WS, c == 0);
     wave_sync();
+    // ---- column cj of dtau/dq, of dtau/dv, and with each the same column of the link rows of da_dx =
+    //      M^-1 [-dtau/dq - K | K | -dtau/dv] (free_fwddyn_asr.py:76-81): the sums of the per-lane evaluation (knot_eval)
+    //      entry by entry, l ascending; operands from LDS, results into the row layout of DYN ----
     double *colL = ML + 8 * c;
+    double *arow = out + dyn_oa_c(NJ) + c;
     rnea_tangent_lds<NJ, 0>(chc, RL, WS, xT + 2 * NJ, cj, colL);
-    if (jl && compute) { ASLR_UNROLL for (int i = 0; i < NJ; ++i) out[2 * NJ + NJ * NJ + i * NJ + c] = colL[i]; }
+    {
+      double Kcol[NJ];
+      ASLR_UNROLL for (int l = 0; l < NJ; ++l) Kcol[l] = dm.m.K[l * NJ + cj];
+      ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+        double sq = 0.0, sk = 0.0;
+        ASLR_UNROLL for (int l = 0; l < NJ; ++l) {
+          const double mi = MiL[8 * l + i];
+          sq += mi * (-colL[l] - Kcol[l]);
+          sk += mi * Kcol[l];
+        }
+        if (jl && compute) { arow[i * dyn_row_c(NJ)] = sq; arow[i * dyn_row_c(NJ) + NJ] = sk; }
+      }
+    }
     rnea_tangent_lds<NJ, 1>(chc, RL, WS, xT + 2 * NJ, cj, colL);
-    if (jl && compute) { ASLR_UNROLL for (int i = 0; i < NJ; ++i) out[2 * NJ + 2 * NJ * NJ + i * NJ + c] = colL[i]; }
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
+      double sv = 0.0;
+      ASLR_UNROLL for (int l = 0; l < NJ; ++l) sv += MiL[8 * l + i] * (-colL[l]);
+      if (jl && compute) arow[i * dyn_row_c(NJ) + 2 * NJ] = sv;
+    }
   }
 }
 

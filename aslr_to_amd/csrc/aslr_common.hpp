@@ -24,8 +24,6 @@ constexpr int kErrLen = 512;
     }                                                                                               \
   } while (0)
 
-// doubles per knot of the DYN region: [xout (2 nj) | M^-1 | dtau/dq | dtau/dv], chains with nj > 2 only
-constexpr int dyn_len_c(int nj) { return nj > 2 ? (2 * nj + 3 * nj * nj + 1) / 2 * 2 : 0; }
 constexpr int rec_len_c(int nx, int nu) { return (2 * nx * nx + 2 * nx * nu + nu * nu + nx + nu + 15) / 16 * 16; }
 
 // kernel argument block: device pointers into the workspace

@@ -223,15 +223,18 @@ ASLR_DEV M3 m3(cdp p) {
 ASLR_DEV SV operator+(SV a, SV b) { return SV{a.lin + b.lin, a.ang + b.ang}; }
 ASLR_DEV SV sv_zero() { return SV{V3{0, 0, 0}, V3{0, 0, 0}}; }
 // Rodrigues rotation about a unit axis (JointModelRevoluteUnaligned)
-ASLR_DEV M3 axis_angle(V3 ax, double q) {
-  double s, c;
-  sincos_fast(q, &s, &c);
+ASLR_DEV M3 axis_angle_sc(V3 ax, double s, double c) {
   const double v = 1.0 - c;
   M3 R;
   R.a[0] = ax.x * ax.x * v + c;        R.a[1] = ax.x * ax.y * v - ax.z * s; R.a[2] = ax.x * ax.z * v + ax.y * s;
   R.a[3] = ax.y * ax.x * v + ax.z * s; R.a[4] = ax.y * ax.y * v + c;        R.a[5] = ax.y * ax.z * v - ax.x * s;
   R.a[6] = ax.z * ax.x * v - ax.y * s; R.a[7] = ax.z * ax.y * v + ax.x * s; R.a[8] = ax.z * ax.z * v + c;
   return R;
+}
+ASLR_DEV M3 axis_angle(V3 ax, double q) {
+  double s, c;
+  sincos_fast(q, &s, &c);
+  return axis_angle_sc(ax, s, c);
 }
 ASLR_DEV SE3d se3_mul(const SE3d &A, const SE3d &B) { return SE3d{mul(A.R, B.R), mul(A.R, B.p) + A.p}; }
 // motion: child -> parent
@@ -579,20 +582,39 @@ struct Chain3D {
     ASLR_UNROLL for (int i = 1; i < NJ; ++i) if (i == fj) r = oMi[i];
     return r;
   }
-  // world placements of all joints without keeping the parent-to-child transforms (cost derivatives when the
-  // dynamics were evaluated elsewhere): same products, same order as setup() + joint_world()
+  // Cost derivatives when the dynamics were evaluated elsewhere: only sin / cos of the joint angles are kept (2 nj
+  // doubles); a joint's world placement is rebuilt as a running product whenever it is needed -- the same products in
+  // the same order as setup() + joint_world(), so the same bits -- instead of holding all nj placements (12 nj doubles,
+  // which with the Jacobian and the cost Hessian of a 7-joint chain did not fit the register file: 4 KB of scratch)
+  double sn_[NJ], cs_[NJ];
+  SE3d run_;
   ASLR_DEV void setup_world(const double *q) {
-    ASLR_UNROLL for (int i = 0; i < NJ; ++i) {
-      SE3d li;
-      li.R = mul(m3(c->joint_R[i]), axis_angle(v3(c->axis[i]), q[i]));
-      li.p = v3(c->joint_p[i]);
-      if (i == 0) oMi[0] = li; else oMi[i] = se3_mul(oMi[i - 1], li);
-    }
+    ASLR_UNROLL for (int i = 0; i < NJ; ++i) sincos_fast(q[i], &sn_[i], &cs_[i]);
+  }
+  ASLR_DEV SE3d local_of(int i) const {
+    SE3d li;
+    li.R = mul(m3(c->joint_R[i]), axis_angle_sc(v3(c->axis[i]), sn_[i], cs_[i]));
+    li.p = v3(c->joint_p[i]);
+    return li;
   }
   ASLR_DEV SE3d joint_world_ready(int fj) const {
-    SE3d r = oMi[0];
-    ASLR_UNROLL for (int i = 1; i < NJ; ++i) if (i == fj) r = oMi[i];
-    return r;
+    SE3d r = local_of(0), o = r;
+    ASLR_UNROLL for (int i = 1; i < NJ; ++i) {
+      if (i <= fj) { // wave-uniform (fj is a constant of the cost)
+        r = se3_mul(r, local_of(i));
+        o = r;
+      }
+    }
+    return o;
+  }
+  // LOCAL frame Jacobian column j after setup_world(): to be called with j = 0, 1, 2, ... in this order (the world
+  // placement of joint j is the running product advanced by one joint per call)
+  ASLR_DEV SV jac_col_seq(int j, const SE3d &oMf) {
+    if (j == 0) run_ = local_of(0); else run_ = se3_mul(run_, local_of(j));
+    SE3d fMj;
+    fMj.R = mulTN(oMf.R, run_.R);
+    fMj.p = mulT(oMf.R, run_.p - oMf.p);
+    return motion_act(fMj, SV{V3{0, 0, 0}, v3(c->axis[j])});
   }
   // world placement of joint fj alone (cost-only evaluations): the same products in the same order as setup() +
   // joint_world(), as a running product -- no per-joint arrays (they cost 3.4 KB of scratch per lane at nj = 7)
@@ -805,6 +827,7 @@ struct ChainPlanar {
   }
   ASLR_DEV void setup_world(const double *q) { setup(q); }
   ASLR_DEV SE3d joint_world_ready(int fj) { return joint_world(fj); }
+  ASLR_DEV SV jac_col_seq(int j, const SE3d &oMf) const { return jac_col(j, oMf); }
   ASLR_DEV static SE3d world_of(const Consts &cc, const double *q, int fj) {
     ChainPlanar ch(cc);
     ch.setup(q);
@@ -852,6 +875,13 @@ struct ChainPlanar {
   }
 };
 
+// DYN record of a knot (region DYN, chains with nj > 2: written by dyn_team_kernel, read by calc_kernel<..., PRE>), doubles:
+//   [ xout (2 nj) | M^-1 (nj x nj, row-major) | pad to even | nj rows [ Aqq[i][:] | Aqm[i][:] | Aqv[i][:] | pad to even ] ]
+// i.e. the link rows of da_dx in the column order of an Fx row, so the record assembly reads them where it needs them
+constexpr int dyn_row_c(int nj) { return (3 * nj + 1) / 2 * 2; }
+constexpr int dyn_oa_c(int nj) { return (2 * nj + nj * nj + 1) / 2 * 2; }
+constexpr int dyn_len_c(int nj) { return nj > 2 ? dyn_oa_c(nj) + nj * dyn_row_c(nj) : 0; }
+
 // ---------------------------------------------------------------------------------------------
 // knot-level results
 // ---------------------------------------------------------------------------------------------
@@ -863,6 +893,11 @@ struct KnotDiff {
   double Aqq[NJ][NJ], Aqm[NJ][NJ], Aqv[NJ][NJ], Bk[NJ][NJ]; // da_dx blocks
   double Ful[NJ][NU], Fum[NJ][NU];                          // da_du link / motor rows
   double Lx[4 * NJ], Lu[NU], Lqq[NJ][NJ], Lxxd[4 * NJ], Luud[NU];
+  // kEvalPre: the link rows of da_dx stay in the knot's DYN record (dyn_team_kernel wrote them); rec_elem<..., LAZY> reads
+  // an entry there when it assembles the record line that holds it, so the 3 nj^2 values are never live together
+  const double *arows;
+  // kEvalLqqMem: where Lqq[j][l] lives instead (element j * NJ + l); rec_elem<..., LAZY> reads it there
+  double *lqq_mem;
 };
 
 template <int NJ, int DAM> struct ModelDims {
@@ -1056,12 +1091,14 @@ struct ModelRegs {
 constexpr int kEvalDyn = 1;  // xnext (dynamics + Euler step)
 constexpr int kEvalCost = 2; // cost
 constexpr int kEvalDiff = 4; // compact derivatives (implies both of the above)
-constexpr int kEvalPre = 8;  // the rigid-body part (xout, M^-1, dtau/dq, dtau/dv) is read from `pre` (DYN region)
+constexpr int kEvalPre = 8;  // the rigid-body part (xout, M^-1, the link rows of da_dx) is read from `pre` (DYN region)
 constexpr int kEvalSkipCost = 16; // with kEvalDiff: dynamics and its derivatives only (first half of a split evaluation)
 constexpr int kEvalSkipDyn = 32;  // with kEvalDiff: cost stack and its derivatives only (second half)
 constexpr int kEvalResid = 64;    // also store the stacked cost residuals (data.r) through `resid`
 constexpr int kEvalFastReach = 128; // cost-only evaluations on a planar chain with PlanarChain::reach_ok: frame-placement
                                     // residuals in closed form (ChainPlanar::reach_residual)
+constexpr int kEvalLqqMem = 256;    // the nj x nj block of Lxx is accumulated in memory (KnotDiff::lqq_mem, e.g. LDS) instead of
+                                    // registers: 2 nj^2 registers that the Jacobian of a 7-joint chain needs at the same time
 
 // calc (+ calcDiff): x[4NJ], u[NU] -> xnext, cost (+ compact derivatives).
 // u == nullptr selects the model's "u is None" default (terminal node).
@@ -1146,27 +1183,30 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
     }
 
     if (DIFF) {
-      double ddq[NJ][NJ], ddv[NJ][NJ];
       if constexpr (PRE) {
+        // the team kernel has formed M^-1 [-dtau/dq - K | K | -dtau/dv] (same sums, same order); only the motor block is left
+        kd->arows = pre + dyn_oa_c(NJ);
         ASLR_UNROLL for (int i = 0; i < NJ; ++i)
           ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
-            ddq[i][j] = pre[2 * NJ + NJ * NJ + i * NJ + j];
-            ddv[i][j] = pre[2 * NJ + 2 * NJ * NJ + i * NJ + j];
+            double bk = 0.0;
+            ASLR_UNROLL for (int l = 0; l < NJ; ++l) bk += mr.Binv[i][l] * Kmat[l][j];
+            kd->Bk[i][j] = bk;
           }
       } else {
+        double ddq[NJ][NJ], ddv[NJ][NJ];
         ch.rnea_derivatives(v, xout, ddq, ddv);
-      }
-      ASLR_UNROLL for (int i = 0; i < NJ; ++i)
-        ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
-          double sq = 0.0, sk = 0.0, sv = 0.0, bk = 0.0;
-          ASLR_UNROLL for (int l = 0; l < NJ; ++l) {
-            sq += Minv[i][l] * (-ddq[l][j] - Kmat[l][j]);
-            sk += Minv[i][l] * Kmat[l][j];
-            sv += Minv[i][l] * (-ddv[l][j]);
-            bk += mr.Binv[i][l] * Kmat[l][j];
+        ASLR_UNROLL for (int i = 0; i < NJ; ++i)
+          ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
+            double sq = 0.0, sk = 0.0, sv = 0.0, bk = 0.0;
+            ASLR_UNROLL for (int l = 0; l < NJ; ++l) {
+              sq += Minv[i][l] * (-ddq[l][j] - Kmat[l][j]);
+              sk += Minv[i][l] * Kmat[l][j];
+              sv += Minv[i][l] * (-ddv[l][j]);
+              bk += mr.Binv[i][l] * Kmat[l][j];
+            }
+            kd->Aqq[i][j] = sq; kd->Aqm[i][j] = sk; kd->Aqv[i][j] = sv; kd->Bk[i][j] = bk;
           }
-          kd->Aqq[i][j] = sq; kd->Aqm[i][j] = sk; kd->Aqv[i][j] = sv; kd->Bk[i][j] = bk;
-        }
+      }
       ASLR_UNROLL for (int i = 0; i < NJ; ++i)
         ASLR_UNROLL for (int j = 0; j < NU; ++j) { kd->Ful[i][j] = 0.0; kd->Fum[i][j] = 0.0; }
       if (DAM == ASLR_DAM_VSA) {
@@ -1191,7 +1231,7 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
     ASLR_UNROLL for (int i = 0; i < NX; ++i) { kd->Lx[i] = 0.0; kd->Lxxd[i] = 0.0; }
     ASLR_UNROLL for (int i = 0; i < NU; ++i) { kd->Lu[i] = 0.0; kd->Luud[i] = 0.0; }
     ASLR_UNROLL for (int i = 0; i < NJ; ++i)
-      ASLR_UNROLL for (int j = 0; j < NJ; ++j) kd->Lqq[i][j] = 0.0;
+      ASLR_UNROLL for (int j = 0; j < NJ; ++j) { if constexpr ((WHAT & kEvalLqqMem) != 0) kd->lqq_mem[i * NJ + j] = 0.0; else kd->Lqq[i][j] = 0.0; }
   }
 
   // ---- cost stack ----
@@ -1235,7 +1275,8 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
         jlog6_shared(rMf, lg, A, Bm);
         double Jr[6][NJ];
         ASLR_UNROLL for (int j = 0; j < NJ; ++j) {
-          SV col = ch.jac_col(j, oMf);
+          SV col;
+          if constexpr (WORLDONLY) col = ch.jac_col_seq(j, oMf); else col = ch.jac_col(j, oMf);
           if (j > fj) col = sv_zero();
           const V3 top = mul(A, col.lin) + mul(Bm, col.ang);
           const V3 bot = mul(A, col.ang);
@@ -1249,7 +1290,7 @@ ASLR_DEV void knot_eval(const typename CH::Consts &cc, const ModelRegs<NJ, Model
           ASLR_UNROLL for (int l = 0; l < NJ; ++l) {
             double hh = 0.0;
             ASLR_UNROLL for (int i = 0; i < 6; ++i) hh += Jr[i][j] * ct.act_w[i] * Jr[i][l];
-            kd->Lqq[j][l] += w * hh;
+            if constexpr ((WHAT & kEvalLqqMem) != 0) kd->lqq_mem[j * NJ + l] += w * hh; else kd->Lqq[j][l] += w * hh;
           }
         }
       }
@@ -1322,7 +1363,7 @@ struct RecLayout {
   static constexpr int len = (oEnd + 15) / 16 * 16;
 };
 
-template <int NJ, int NU, int E>
+template <int NJ, int NU, int E, bool LAZY = false>
 ASLR_DEV double rec_elem(const KnotDiff<NJ, NU> &k, double dt) {
   using L = RecLayout<NJ, NU>;
   constexpr int NX = L::NX, NV = L::NV;
@@ -1331,10 +1372,11 @@ ASLR_DEV double rec_elem(const KnotDiff<NJ, NU> &k, double dt) {
     constexpr int ri = r % NV; // row of da_dx
     double a; // da_dx[ri][cc]
     if constexpr (ri < NJ) {
-      if constexpr (cc < NJ) a = k.Aqq[ri][cc];
+      if constexpr (cc >= 3 * NJ) a = 0.0;
+      else if constexpr (LAZY) a = k.arows[ri * dyn_row_c(NJ) + cc]; // (a DYN row is [Aqq | Aqm | Aqv] of that row)
+      else if constexpr (cc < NJ) a = k.Aqq[ri][cc];
       else if constexpr (cc < 2 * NJ) a = k.Aqm[ri][cc - NJ];
-      else if constexpr (cc < 3 * NJ) a = k.Aqv[ri][cc - 2 * NJ];
-      else a = 0.0;
+      else a = k.Aqv[ri][cc - 2 * NJ];
     } else {
       if constexpr (cc < NJ) a = k.Bk[ri - NJ][cc];
       else if constexpr (cc < 2 * NJ) a = -k.Bk[ri - NJ][cc - NJ];
@@ -1359,7 +1401,7 @@ ASLR_DEV double rec_elem(const KnotDiff<NJ, NU> &k, double dt) {
   } else if constexpr (E < L::oLxu) {
     constexpr int e = E - L::oLxx, r = e / NX, cc = e % NX;
     double val = 0.0;
-    if constexpr (r < NJ && cc < NJ) val = k.Lqq[r][cc];
+    if constexpr (r < NJ && cc < NJ) { if constexpr (LAZY) val = k.lqq_mem[r * NJ + cc]; else val = k.Lqq[r][cc]; }
     if constexpr (r == cc) val += k.Lxxd[r];
     return val;
   } else if constexpr (E < L::oLuu) {
