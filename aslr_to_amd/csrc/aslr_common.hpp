@@ -43,6 +43,10 @@ struct KArgs {
   int32_t planar_reach; // ... and the frame-placement costs for the closed-form residual (DevDesc::planar.reach_ok)
   double *iter_log;  // per-iteration log [log_cap][ASLR_LOG_COUNT][B] (aslr_set_iteration_log), or nullptr
   int32_t log_cap;
+  // knots [seg_t0, seg_t1] of the horizon this launch covers (kernels that can work on a part of it: the rollout carries
+  // its state over through the candidate it has stored; the trial costs are per knot): the whole horizon = [0, T]
+  int32_t seg_t0, seg_t1;
+  int32_t pipeline; // split the forward pass so that the trial costs of the first half run under the rollout of the second
 };
 
 // Line-search candidates (XS_TRY / US_TRY, layout in include/aslr_to_amd.h): 16-byte piece p of trajectory b at knot t of

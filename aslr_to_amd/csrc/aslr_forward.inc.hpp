@@ -22,14 +22,17 @@ namespace aslr {
 
 // FDDP: the gap-contracting rollout and the dv terms of SolverFDDP are compiled in (two more 8-double prefetch
 // buffers per lane); the DDP / BoxDDP variant does not carry them.
+// Knots [s0, s1] of the horizon (the whole of it: [0, T]): a launch that starts at s0 > 0 continues the rollout a previous
+// launch stopped at s0 -- state from the candidate stored there, dv / failure flag from the per-trajectory slots -- and
+// repeats nothing that launch has already accounted for at knot s0 (gap contraction, the dv term).
 template <int NJ, int DAM, bool PLANAR, bool FDDP>
-__global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
+ASLR_DEV void rollout_body(const KArgs &a, const SolverDev &sp, const ModelLimits &lim, int vblock, int s0, int s1) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
   constexpr int TEAM = 16, TPW = ASLR_ROLLOUT_TPW;
   using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
   const int lane = threadIdx.x, team = lane / TEAM, al = lane % TEAM;
   const int B = a.B, T = a.T;
-  const int bq = a.b0 + blockIdx.x * TPW + team;
+  const int bq = a.b0 + vblock * TPW + team;
   const bool team_valid = team < TPW && bq < a.b1;
   const int b = team_valid ? bq : a.b1 - 1;
   int32_t *TI = a.traj_i;
@@ -48,9 +51,17 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
 
   double x[NX], dv = 0.0;
   bool fail = false;
-  {
+  const bool cont = s0 > 0;
+  if (!cont) {
     const double *x0 = a.x0 + (size_t)b * NX;
     ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = x0[i];
+  } else {
+    ASLR_UNROLL for (int p = 0; p < NX / 2; ++p) {
+      const double2 v = *reinterpret_cast<const double2 *>(a.xs_try + cand_piece<NX>(ai, s0, b, p, B, T + 1));
+      x[2 * p] = v.x; x[2 * p + 1] = v.y;
+    }
+    dv = TF[(ASLR_TF_DVTRY0 + ai) * B + b];
+    fail = TI[(ASLR_TI_TRYFAIL0 + ai) * B + b] != 0;
   }
   const typename CH::Consts cc(D, true); // (true: this kernel loops over knots -- sin / cos constants in registers)
   ModelRegs<NJ, NU> mr;
@@ -89,20 +100,21 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
     }
     mi_next = node_model_at(a, t);
   };
-  prefetch(0);
-  for (int t = 0; t <= T; ++t) {
+  prefetch(s0);
+  for (int t = s0; t <= s1; ++t) {
     // inputs of knot t have landed (issued one knot ago, before that knot's NST candidate stores)
-    if (t == 0) wait_vmcnt<0>(); else wait_vmcnt<NST>();
+    if (t == s0) wait_vmcnt<0>(); else wait_vmcnt<NST>();
+    const bool seam = cont && t == s0; // the previous launch has been here
     wave_sync();
     const double *stgT = stgD[t & 1] + team * BS;
     auto S = [&](int e) -> double { return stgT[(e / BS) * DMAW + e % BS]; };
     const int mi = mi_next;
-    if (t < T) prefetch(t + 1); // in flight while knot t computes (the other parity buffer: its readers finished
-                                // before the wave_sync above)
+    if (t < s1) prefetch(t + 1); // in flight while knot t computes (the other parity buffer: its readers finished
+                                 // before the wave_sync above)
     double dx[NX];
-    if (use_gaps) { ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = x[i] + S(oFg + i) * (alpha - 1.0); }
+    if (use_gaps && !seam) { ASLR_UNROLL for (int i = 0; i < NX; ++i) x[i] = x[i] + S(oFg + i) * (alpha - 1.0); }
     ASLR_UNROLL for (int i = 0; i < NX; ++i) dx[i] = x[i] - S(oXr + i);
-    if (need_dv) { // dv -= fs . Vxx (xs - xs_try)
+    if (need_dv && !seam) { // dv -= fs . Vxx (xs - xs_try)
       double s = 0.0;
       ASLR_UNROLL for (int i = 0; i < NX; ++i) s += S(oVf + i) * (S(oXr + i) - x[i]);
       dv -= s;
@@ -111,7 +123,7 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
       ASLR_UNROLL for (int p = 0; p < NX / 2; ++p)
         *reinterpret_cast<double2 *>(a.xs_try + cand_piece<NX>(ai, t, b, p, B, T + 1)) = make_double2(x[2 * p], x[2 * p + 1]);
     }
-    if (t == T) break;
+    if (t == s1) break; // (the state of knot s1 is stored: a later launch continues from it; s1 = T: the terminal state)
     double u[NU];
     ASLR_UNROLL for (int i = 0; i < NU; ++i) {
       double s = S(oU + i) - S(oKf + i) * alpha;
@@ -144,15 +156,19 @@ __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, Mode
     TF[(ASLR_TF_DVTRY0 + ai) * B + b] = dv;
   }
 }
+template <int NJ, int DAM, bool PLANAR, bool FDDP>
+__global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
+  rollout_body<NJ, DAM, PLANAR, FDDP>(a, sp, lim, blockIdx.x, a.seg_t0, a.seg_t1);
+}
 
 // cost of every stored candidate knot: COST_TRY[a][t][b]
 // FAST (planar chains with PlanarChain::reach_ok): closed-form frame-placement residual
 template <int NJ, int DAM, bool PLANAR, bool FAST = false>
-__global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
+ASLR_DEV void trial_cost_body(const KArgs &a, const SolverDev &sp, int vbx, int t, int ai) {
   constexpr int NX = 4 * NJ, NU = ModelDims<NJ, DAM>::nu;
   using CH = std::conditional_t<PLANAR, ChainPlanar<NJ>, Chain3D<NJ>>;
-  const int B = a.B, T = a.T, t = blockIdx.y, ai = blockIdx.z;
-  const int bq = a.b0 + blockIdx.x * 64 + threadIdx.x;
+  const int B = a.B, T = a.T;
+  const int bq = a.b0 + vbx * 64 + threadIdx.x;
   const bool valid = bq < a.b1;
   const int b = valid ? bq : a.b1 - 1;
   const int done = sp.standalone ? 0 : a.traj_i[ASLR_TI_DONE * B + b];
@@ -186,6 +202,24 @@ __global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
   mr.load(dm);
   knot_eval<NJ, DAM, kEvalCost | (FAST && PLANAR ? kEvalFastReach : 0), CH>(cc, mr, dm, fref, x, t < T ? u : nullptr, xnext, c, nullptr);
   a.cost_try[(size_t)ai * TB1 + tb] = c;
+}
+// grid (ceil(nb / 64), knots of the segment, step lengths): knots a.seg_t0 + blockIdx.y
+template <int NJ, int DAM, bool PLANAR, bool FAST = false>
+__global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
+  trial_cost_body<NJ, DAM, PLANAR, FAST>(a, sp, blockIdx.x, a.seg_t0 + blockIdx.y, blockIdx.z);
+}
+// One launch, two roles: blocks [0, nroll) continue the rollout over the knots [r0, r1] while the others evaluate the trial
+// costs of the knots [c0, c0 + cknots) the previous rollout launch has stored (block order = dispatch order: the sweep waves
+// take their SIMDs first, the cost waves fill in next to them).  Cost block v - nroll = (x, knot, step length), x fastest.
+template <int NJ, int DAM, bool PLANAR, bool FDDP, bool FAST>
+__global__ void __launch_bounds__(64) rollout_and_cost_kernel(KArgs a, SolverDev sp, ModelLimits lim, int nroll, int r0, int r1,
+                                                              int cgx, int c0, int cknots) {
+  if ((int)blockIdx.x < nroll) {
+    rollout_body<NJ, DAM, PLANAR, FDDP>(a, sp, lim, blockIdx.x, r0, r1);
+  } else {
+    const int v = blockIdx.x - nroll, vx = v % cgx, rest = v / cgx;
+    trial_cost_body<NJ, DAM, PLANAR, FAST>(a, sp, vx, c0 + rest % cknots, rest / cknots);
+  }
 }
 
 // cost_try of each candidate: its node costs summed in rollout order, one lane per (trajectory, alpha);
