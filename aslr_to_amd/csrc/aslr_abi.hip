@@ -546,7 +546,7 @@ int aslr_problem_create(const aslr_problem_desc_t *desc, void *workspace, int64_
   k.planar_reach = planar_reach;
   k.iter_log = nullptr; k.log_cap = 0;
   k.seg_t0 = 0; k.seg_t1 = desc->T;
-  k.pipeline = getenv("ASLR_PIPELINE") ? atoi(getenv("ASLR_PIPELINE")) : 0;
+  k.pipeline = getenv("ASLR_PIPELINE") ? atoi(getenv("ASLR_PIPELINE")) : 1; // (read once, when the handle is created)
   *out = p;
   return ASLR_OK;
 }

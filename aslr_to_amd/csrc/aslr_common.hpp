@@ -46,7 +46,8 @@ struct KArgs {
   // knots [seg_t0, seg_t1] of the horizon this launch covers (kernels that can work on a part of it: the rollout carries
   // its state over through the candidate it has stored; the trial costs are per knot): the whole horizon = [0, T]
   int32_t seg_t0, seg_t1;
-  int32_t pipeline; // split the forward pass so that the trial costs of the first half run under the rollout of the second
+  int32_t pipeline; // forward pass in two launches: the trial costs of the first half of the horizon run in the launch that rolls
+                    // out the second half (rollout_and_cost_kernel; planar 2-joint chains).  ASLR_PIPELINE=0 turns it off
 };
 
 // Line-search candidates (XS_TRY / US_TRY, layout in include/aslr_to_amd.h): 16-byte piece p of trajectory b at knot t of
