@@ -47,7 +47,7 @@ struct KArgs {
   // its state over through the candidate it has stored; the trial costs are per knot): the whole horizon = [0, T]
   int32_t seg_t0, seg_t1;
   int32_t pipeline; // forward pass in two launches: the trial costs of the first half of the horizon run in the launch that rolls
-                    // out the second half (rollout_and_cost_kernel; planar 2-joint chains).  ASLR_PIPELINE=0 turns it off
+                    // out the second half (rollout_and_cost_kernel; planar 2-joint chains).  0: off, 1 or 2: two segments (default), 3, 4: more (measured: no better)
 };
 
 // Line-search candidates (XS_TRY / US_TRY, layout in include/aslr_to_amd.h): 16-byte piece p of trajectory b at knot t of

@@ -22,20 +22,25 @@ void launch_forward_t(const KArgs &k, const SolverDev &sd, const ModelLimits &li
     }
     hipLaunchKernelGGL((trial_cost_kernel<2, DAM, PLANAR, false>), cgrid, block, 0, st, a, sd);
   };
-  if (PLANAR && k.pipeline && !fast && T >= 16) {
-    // rollout of the first half; then ONE launch in which the rollout continues over the second half while the trial costs
-    // of the first half are evaluated next to it; then the trial costs of the second half
-    const int Tm = T / 2;
+  const int nseg = k.pipeline >= 2 ? (k.pipeline <= 4 ? k.pipeline : 4) : (k.pipeline == 1 ? 2 : 1); // (1: two segments, n >= 2: n)
+  if (PLANAR && nseg > 1 && !fast && T >= 16) {
+    // rollout of the first segment; then launches in which the rollout continues over the next segment while the trial costs
+    // of the previous one are evaluated next to it; then the trial costs of the last segment
+    int lo = 0, hi = T / nseg;
     KArgs a = k;
-    a.seg_t0 = 0; a.seg_t1 = Tm;
+    a.seg_t0 = lo; a.seg_t1 = hi;
     rollout(a);
-    const int ncost = cgx * Tm * ASLR_NALPHA; // knots 0 .. Tm-1
-    const dim3 fgrid(grid.x + ncost);
-    if constexpr (PLANAR) {
-      if (fddp) hipLaunchKernelGGL((rollout_and_cost_kernel<2, DAM, true, true, false>), fgrid, block, 0, st, k, sd, lim, (int)grid.x, Tm, T, cgx, 0, Tm);
-      else hipLaunchKernelGGL((rollout_and_cost_kernel<2, DAM, true, false, false>), fgrid, block, 0, st, k, sd, lim, (int)grid.x, Tm, T, cgx, 0, Tm);
+    for (int sgm = 1; sgm < nseg; ++sgm) {
+      const int nlo = hi, nhi = sgm == nseg - 1 ? T : (T * (sgm + 1)) / nseg; // rollout [nlo, nhi], costs of the knots [lo, nlo)
+      const int ncost = cgx * (nlo - lo) * ASLR_NALPHA;
+      const dim3 fgrid(grid.x + ncost);
+      if constexpr (PLANAR) {
+        if (fddp) hipLaunchKernelGGL((rollout_and_cost_kernel<2, DAM, true, true, false>), fgrid, block, 0, st, k, sd, lim, (int)grid.x, nlo, nhi, cgx, lo, nlo - lo);
+        else hipLaunchKernelGGL((rollout_and_cost_kernel<2, DAM, true, false, false>), fgrid, block, 0, st, k, sd, lim, (int)grid.x, nlo, nhi, cgx, lo, nlo - lo);
+      }
+      lo = nlo; hi = nhi;
     }
-    a.seg_t0 = Tm; a.seg_t1 = T;
+    a.seg_t0 = lo; a.seg_t1 = T;
     costs(a);
   } else {
     rollout(k);
