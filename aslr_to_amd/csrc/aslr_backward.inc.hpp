@@ -327,6 +327,9 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : (BwdCfg<NX, NU
 
   int32_t *TI = a.traj_i;
   double *TF = a.traj_f;
+#ifdef ASLR_EXP_WAVETIME
+  const long long exp_t0 = wall_clock64();
+#endif
 
   // ---- prologue: solver-state bookkeeping that Crocoddyl does inside calcDiff ----
   int done = 0, feasible = TI[ASLR_TI_FEASIBLE * B + b], status = TI[ASLR_TI_STATUS * B + b];
@@ -836,6 +839,10 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : (BwdCfg<NX, NU
   }
 #endif
   ASLR_PROF_FLUSH;
+#ifdef ASLR_EXP_WAVETIME
+  // (experiment: how long each wave of the sweep ran, 100 MHz ticks, into the unused head of VX -- tools/wave_times.py)
+  if (threadIdx.x == 0) a.vx[blockIdx.x] = (double)(wall_clock64() - exp_t0);
+#endif
 }
 
 // `all_feasible`: the caller knows every trajectory of the shard is feasible (no gap terms needed)
