@@ -51,7 +51,7 @@ WORKLOADS = {
                metric="knot-steps/s (batched DDP, 2-DoF SEA, T=100, 1024 trajectories per GPU)",
                what="two_dof_sea (examples/two_dof_sea.py, T=100): SolverDDP (north_star; the script itself uses FDDP), "
                     "cold start, fixed-iteration mode, full 10-alpha line search every iteration",
-               kernels=["calc_kernel<2, 0, true, true, false, true>", "backward_kernel<8, 2, 2, 0, false, true>",
+               kernels=["calc_kernel<2, 0, true, true, false, true>", "backward_kernel<8, 2, 4, 0, false, true>",
                         "rollout_kernel<2, 0, true, false>"],
                cpu=dict(per_thread=256, single=128, maxiter=None)),
     "c5": dict(scenario="talos_arm_sea", solver="SolverDDP", T=150, batch=512,
