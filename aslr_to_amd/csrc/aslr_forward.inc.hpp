@@ -10,6 +10,10 @@
 //   select_kernel      one lane per trajectory: sums the node costs of each candidate in rollout order,
 //                      takes the FIRST acceptable alpha in Crocoddyl's order and updates the solver state
 //                      (feasibility, cost, regularisation schedule, stop, status).
+//
+// The rollout and the trial costs take a SEGMENT of the horizon (KArgs::seg_t0 / seg_t1), and rollout_and_cost_kernel is one
+// launch with both roles: its first blocks roll out a segment, the others evaluate the trial costs of the segment before.
+// The launchers (aslr_forward_nj2.hip) use it to take half of the trial costs off the latency chain of an iteration.
 #pragma once
 #include "aslr_common.hpp"
 
