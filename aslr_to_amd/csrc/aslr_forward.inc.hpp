@@ -344,6 +344,15 @@ __global__ void __launch_bounds__(64) select_kernel(KArgs a, SolverDev sp) {
   TF[ASLR_TF_DV * B + b] = dV;
   TF[ASLR_TF_DVEXP * B + b] = dVexp;
   if (fddp) { TF[ASLR_TF_D1 * B + b] = d1; TF[ASLR_TF_D2 * B + b] = d2; }
+#ifdef ASLR_EXP_STAMP
+  // (experiment: when did this launch end / the next calc launch of the sub-shard start -- stamps in the unused head of VXX)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long *w = reinterpret_cast<unsigned long long *>(a.vxx) + (size_t)(a.b0 * 4 / a.B) * 512;
+    const unsigned long long slot = w[511];
+    if (slot < 100) w[2 * slot] = (unsigned long long)wall_clock64();
+    w[511] = slot + 1;
+  }
+#endif
 }
 
 } // namespace aslr
