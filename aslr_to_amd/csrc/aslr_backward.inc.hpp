@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : (BwdCfg<NX, NU
 
   int32_t *TI = a.traj_i;
   double *TF = a.traj_f;
+  ASLR_STAMP_BEGIN(a, 1);
 #ifdef ASLR_EXP_WAVETIME
   const long long exp_t0 = wall_clock64();
 #endif
@@ -839,6 +840,7 @@ __global__ void __launch_bounds__(64, (HS >= 4 ? ASLR_BWD_WAVES : (BwdCfg<NX, NU
   }
 #endif
   ASLR_PROF_FLUSH;
+  ASLR_STAMP_END(1, true);
 #ifdef ASLR_EXP_WAVETIME
   // (experiment: how long each wave of the sweep ran, 100 MHz ticks, into the unused head of VX -- tools/wave_times.py)
   if (threadIdx.x == 0) a.vx[blockIdx.x] = (double)(wall_clock64() - exp_t0);

@@ -30,13 +30,7 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
   __shared__ double lqqL[PRE ? 64 * (NJ * NJ) : 1];
 
   const int lane = threadIdx.x, t = blockIdx.y, B = a.B, T = a.T;
-#ifdef ASLR_EXP_STAMP
-  if (threadIdx.x == 0 && DIFF) {
-    unsigned long long *w = reinterpret_cast<unsigned long long *>(a.vxx) + (size_t)(a.b0 * 4 / a.B) * 512;
-    const unsigned long long slot = *reinterpret_cast<volatile unsigned long long *>(w + 511);
-    if (slot >= 1 && slot <= 100) atomicMin(w + 2 * (slot - 1) + 1, (unsigned long long)wall_clock64());
-  }
-#endif
+  ASLR_STAMP_BEGIN(a, 0);
   const int b0 = a.b0 + blockIdx.x * 64, bq = b0 + lane; // (b0: first trajectory of this block)
   const bool valid = bq < a.b1;
   const int b = valid ? bq : a.b1 - 1;
@@ -214,6 +208,7 @@ __global__ void __launch_bounds__(64, ASLR_CALC_WAVES) calc_kernel(KArgs a, int 
   ASLR_PROF_COUNT(15);
   ASLR_PROF_FLUSH;
   }
+  ASLR_STAMP_END(0, false);
 }
 
 // ShootingProblem.quasiStatic (examples/two_dof_sea.py:78): Crocoddyl's base-class

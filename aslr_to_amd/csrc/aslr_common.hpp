@@ -50,6 +50,32 @@ struct KArgs {
                     // out the second half (rollout_and_cost_kernel; planar 2-joint chains).  0: off, 1 or 2: two segments (default), 3, 4: more (measured: no better)
 };
 
+// -DASLR_EXP_STAMP (tools/stamp_gaps.py): every kernel of an iteration records when its first wave started and its last one
+// ended (s_memrealtime, 100 MHz) in the unused head of VXX: per sub-shard (quarter of the shard) 1024 words,
+// [iteration][kernel 0..7][first start, last end]; word 1023 counts the iterations (select_kernel, the last kernel, bumps it).
+#ifdef ASLR_EXP_STAMP
+// (start: the first block of the grid -- blocks are dispatched in order; end: an atomic max over the blocks of the sweeps, whose
+//  waves all run at once, and the LAST block of the large streaming grids, where 16 000 atomics on one word would be the kernel)
+#define ASLR_STAMP_BEGIN(a, kid)                                                                                       \
+  unsigned long long *stamp_w_ = reinterpret_cast<unsigned long long *>((a).vxx) + (size_t)((a).b0 * 4 / (a).B) * 1024;  \
+  const unsigned long long stamp_it_ = *reinterpret_cast<volatile unsigned long long *>(stamp_w_ + 1023);               \
+  if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && stamp_it_ < 60)                     \
+    stamp_w_[(stamp_it_ * 8 + (kid)) * 2] = (unsigned long long)wall_clock64()
+#define ASLR_STAMP_END(kid, every_block)                                                                               \
+  do {                                                                                                                 \
+    if (threadIdx.x == 0 && stamp_it_ < 60) {                                                                          \
+      if (every_block) atomicMax(stamp_w_ + (stamp_it_ * 8 + (kid)) * 2 + 1, (unsigned long long)wall_clock64());      \
+      else if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1)              \
+        stamp_w_[(stamp_it_ * 8 + (kid)) * 2 + 1] = (unsigned long long)wall_clock64();                                \
+    }                                                                                                                  \
+  } while (0)
+#define ASLR_STAMP_NEXT() do { if (blockIdx.x == 0 && threadIdx.x == 0) stamp_w_[1023] = stamp_it_ + 1; } while (0)
+#else
+#define ASLR_STAMP_BEGIN(a, kid)
+#define ASLR_STAMP_END(kid, every_block)
+#define ASLR_STAMP_NEXT()
+#endif
+
 // Line-search candidates (XS_TRY / US_TRY, layout in include/aslr_to_amd.h): 16-byte piece p of trajectory b at knot t of
 // step length ai; W = doubles per candidate, TK = knots stored (T + 1 or T)
 template <int W>

@@ -162,7 +162,9 @@ ASLR_DEV void rollout_body(const KArgs &a, const SolverDev &sp, const ModelLimit
 }
 template <int NJ, int DAM, bool PLANAR, bool FDDP>
 __global__ void __launch_bounds__(64) rollout_kernel(KArgs a, SolverDev sp, ModelLimits lim) {
+  ASLR_STAMP_BEGIN(a, 2);
   rollout_body<NJ, DAM, PLANAR, FDDP>(a, sp, lim, blockIdx.x, a.seg_t0, a.seg_t1);
+  ASLR_STAMP_END(2, true);
 }
 
 // cost of every stored candidate knot: COST_TRY[a][t][b]
@@ -210,7 +212,9 @@ ASLR_DEV void trial_cost_body(const KArgs &a, const SolverDev &sp, int vbx, int 
 // grid (ceil(nb / 64), knots of the segment, step lengths): knots a.seg_t0 + blockIdx.y
 template <int NJ, int DAM, bool PLANAR, bool FAST = false>
 __global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
+  ASLR_STAMP_BEGIN(a, 4);
   trial_cost_body<NJ, DAM, PLANAR, FAST>(a, sp, blockIdx.x, a.seg_t0 + blockIdx.y, blockIdx.z);
+  ASLR_STAMP_END(4, false);
 }
 // One launch, two roles: blocks [0, nroll) continue the rollout over the knots [r0, r1] while the others evaluate the trial
 // costs of the knots [c0, c0 + cknots) the previous rollout launch has stored (block order = dispatch order: the sweep waves
@@ -218,11 +222,14 @@ __global__ void __launch_bounds__(64) trial_cost_kernel(KArgs a, SolverDev sp) {
 template <int NJ, int DAM, bool PLANAR, bool FDDP, bool FAST>
 __global__ void __launch_bounds__(64) rollout_and_cost_kernel(KArgs a, SolverDev sp, ModelLimits lim, int nroll, int r0, int r1,
                                                               int cgx, int c0, int cknots) {
+  ASLR_STAMP_BEGIN(a, 3);
   if ((int)blockIdx.x < nroll) {
     rollout_body<NJ, DAM, PLANAR, FDDP>(a, sp, lim, blockIdx.x, r0, r1);
+    ASLR_STAMP_END(3, true);
   } else {
     const int v = blockIdx.x - nroll, vx = v % cgx, rest = v / cgx;
     trial_cost_body<NJ, DAM, PLANAR, FAST>(a, sp, vx, c0 + rest % cknots, rest / cknots);
+    ASLR_STAMP_END(3, false);
   }
 }
 
@@ -230,6 +237,7 @@ __global__ void __launch_bounds__(64) rollout_and_cost_kernel(KArgs a, SolverDev
 // all T+1 loads of a lane are independent, only the adds are ordered
 template <int TAG>
 __global__ void __launch_bounds__(64) sum_cost_kernel(KArgs a, SolverDev sp) {
+  ASLR_STAMP_BEGIN(a, 5);
   const int B = a.B, T = a.T, s = blockIdx.y;
   const int b = a.b0 + blockIdx.x * 64 + threadIdx.x;
   if (b >= a.b1) return;
@@ -245,11 +253,13 @@ __global__ void __launch_bounds__(64) sum_cost_kernel(KArgs a, SolverDev sp) {
   for (; t <= T; ++t) acc += src[(size_t)t * B];
   const bool fail = a.traj_i[(ASLR_TI_TRYFAIL0 + s) * B + b] || is_bad(acc);
   a.traj_f[(ASLR_TF_COST_TRY0 + s) * B + b] = fail ? NAN : acc;
+  ASLR_STAMP_END(5, true);
 }
 
 // line search + solver-state update, one lane per trajectory (model independent)
 template <int TAG>
 __global__ void __launch_bounds__(64) select_kernel(KArgs a, SolverDev sp) {
+  ASLR_STAMP_BEGIN(a, 6);
   const int B = a.B;
   const int b = a.b0 + blockIdx.x * 64 + threadIdx.x;
   if (b >= a.b1) return;
@@ -344,15 +354,8 @@ __global__ void __launch_bounds__(64) select_kernel(KArgs a, SolverDev sp) {
   TF[ASLR_TF_DV * B + b] = dV;
   TF[ASLR_TF_DVEXP * B + b] = dVexp;
   if (fddp) { TF[ASLR_TF_D1 * B + b] = d1; TF[ASLR_TF_D2 * B + b] = d2; }
-#ifdef ASLR_EXP_STAMP
-  // (experiment: when did this launch end / the next calc launch of the sub-shard start -- stamps in the unused head of VXX)
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    unsigned long long *w = reinterpret_cast<unsigned long long *>(a.vxx) + (size_t)(a.b0 * 4 / a.B) * 512;
-    const unsigned long long slot = w[511];
-    if (slot < 100) w[2 * slot] = (unsigned long long)wall_clock64();
-    w[511] = slot + 1;
-  }
-#endif
+  ASLR_STAMP_END(6, true);
+  ASLR_STAMP_NEXT();
 }
 
 } // namespace aslr
