@@ -21,9 +21,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.exit(0)
 B = sys.argv[1] if len(sys.argv) > 1 else "4096"
 N = sys.argv[2] if len(sys.argv) > 2 else "25"
+ENV = os.environ.get("CHECK_ENV", "ASLR_PIPELINE")  # the switch to compare 0 against 1
 for name, solver in (("two_dof_vsa_boxddp", "SolverBoxDDP"), ("two_dof_sea", "SolverFDDP"), ("two_dof_sea", "SolverDDP")):
     out = []
     for pl in ("0", "1"):
-        env = dict(os.environ, ASLR_PIPELINE=pl)
+        env = dict(os.environ, **{ENV: pl})
         out.append(subprocess.run([sys.executable, __file__, "--child", B, N, name, solver], env=env, capture_output=True, text=True).stdout.strip().split("\n")[-1])
     print(name, solver, "identical" if out[0] == out[1] and len(out[0]) == 64 else "DIFFERENT", out)
