@@ -465,17 +465,18 @@ def test_engine_runs_on_its_own_device_whatever_the_current_one():
     assert torch.isfinite(e.region(_abi.R_COST)).all()
 
 
-@pytest.mark.parametrize("name, solver", [("two_dof_vsa_boxddp", "SolverBoxDDP"), ("two_dof_sea", "SolverFDDP")])
-def test_the_two_launch_forward_pass_changes_the_schedule_not_the_results(monkeypatch, name, solver):
+@pytest.mark.parametrize("name, solver, T", [("two_dof_vsa_boxddp", "SolverBoxDDP", 100), ("two_dof_sea", "SolverFDDP", 100),
+                                             ("two_dof_sea", "SolverFDDP", 17), ("two_dof_vsa_boxddp", "SolverBoxDDP", 33)])
+def test_the_two_launch_forward_pass_changes_the_schedule_not_the_results(monkeypatch, name, solver, T):
     """Default: the rollout stops at mid-horizon and a second launch continues it while its other blocks evaluate the trial
     costs of the first half (rollout_and_cost_kernel).  ASLR_PIPELINE=0 (read when the handle is created) is the plain
     sequence; both must give the same bits -- states, controls, gains, solver state -- with and without sub-shards."""
     import torch
     from aslr_to_amd.engine import Engine
     res = {}
-    for pl in ("0", "1"):
+    for pl in ("0", "1", "3"):   # plain sequence, two segments (default), three
         monkeypatch.setenv("ASLR_PIPELINE", pl)
-        sc = scenarios.SCENARIOS[name](B=300, T=100, seed=2)
+        sc = scenarios.SCENARIOS[name](B=300, T=T, seed=2)   # (odd horizons: the seam is at T // 2)
         e = Engine(scenarios.lower(sc))
         e.set_candidate(None, None)
         e.set_subshards(2 if pl == "1" else 1)
@@ -483,9 +484,10 @@ def test_the_two_launch_forward_pass_changes_the_schedule_not_the_results(monkey
         e.iterate_n(sp, True, 12)
         torch.cuda.synchronize()
         res[pl] = [e.region(r).clone() for r in (_abi.R_XS, _abi.R_US, _abi.R_KGAIN, _abi.R_TRAJ_F, _abi.R_TRAJ_I, _abi.R_COST_TRY)]
-    for a, b in zip(res["0"], res["1"]):  # (bit patterns: failed candidates carry NaN)
-        ia, ib = (t.view(torch.int64) if t.dtype == torch.float64 else t for t in (a, b))
-        assert torch.equal(ia, ib)
+    for other in ("1", "3"):
+        for a, b in zip(res["0"], res[other]):  # (bit patterns: failed candidates carry NaN)
+            ia, ib = (t.view(torch.int64) if t.dtype == torch.float64 else t for t in (a, b))
+            assert torch.equal(ia, ib)
     assert int(res["1"][4][_abi.TI_ITER].min()) == 12
 
 
